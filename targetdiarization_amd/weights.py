@@ -1,0 +1,179 @@
+"""Weight catalogue, deterministic recipe weights and the TDXW blob format.
+
+* `mossformer2_param_shapes` restates the state_dict layout of the reference's
+  MossFormer2 (reference: look2hear/models/mossformer2.py:532-561 and the sub-modules it
+  builds; key list verified against the imported reference by oracle/make_goldens.py).
+* `recipe_state_dict` fills that layout from a counter-based PRNG (Philox keyed by the
+  tensor *name*), so the 223 MB of fp32 weights never have to be committed or shipped:
+  the oracle, the tests and bench.py all regenerate bit-identical weights.
+  No trained checkpoint ships with the reference (checkpoints/ holds only .gitkeep).
+* `pack_blob` serialises {name: tensor} into the flat "TDXW" container that the C-ABI
+  (`tdx_mf2_create`, include/tdx.h) parses by tensor name.  A real checkpoint
+  (base_model.py:52-64 format: {"model_name", "state_dict"}) goes through the same packer.
+"""
+from __future__ import annotations
+
+import struct
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+_PFX = "mask_net.mdl.intra_mdl.mossformerM."
+
+
+def mossformer2_param_shapes(num_blocks: int = 24, d: int = 512, kernel_size: int = 16,
+                             num_spks: int = 2, qk_dim: int = 128, expansion: int = 4,
+                             inner: int = 256, rot_dim: int = 32) -> "OrderedDict[str, tuple]":
+    """Ordered {state_dict key: shape}; same key order as the reference's nn.Module."""
+    hid = d * expansion
+    s = OrderedDict()
+    s["enc.conv1d.weight"] = (d, 1, kernel_size)
+    s["mask_net.norm.weight"] = (d,)
+    s["mask_net.norm.bias"] = (d,)
+    s["mask_net.conv1d_encoder.weight"] = (d, d, 1)
+    s["mask_net.pos_enc.scale"] = (1,)
+    s["mask_net.pos_enc.inv_freq"] = (d // 2,)
+    for l in range(num_blocks):
+        p = f"{_PFX}fsmn.{l}."
+        s[p + "conv1.0.weight"] = (inner, d, 1)
+        s[p + "conv1.0.bias"] = (inner,)
+        s[p + "conv1.1.weight"] = (1,)
+        s[p + "norm1.weight"] = (inner,)
+        s[p + "norm1.bias"] = (inner,)
+        for br in ("to_u", "to_v"):
+            q = p + f"gated_fsmn.{br}.mdl."
+            s[q + "0.weight"] = (inner,)
+            s[q + "0.bias"] = (inner,)
+            s[q + "1.weight"] = (inner, inner)
+            s[q + "1.bias"] = (inner,)
+            s[q + "3.sequential.1.conv.weight"] = (inner, 1, 17)
+        q = p + "gated_fsmn.fsmn."
+        s[q + "linear.weight"] = (inner, inner)
+        s[q + "linear.bias"] = (inner,)
+        s[q + "project.weight"] = (inner, inner)
+        s[q + "conv.conv1.weight"] = (inner, 1, 39, 1)
+        s[q + "conv.norm1.weight"] = (inner,)
+        s[q + "conv.norm1.bias"] = (inner,)
+        s[q + "conv.prelu1.weight"] = (inner,)
+        s[q + "conv.conv2.weight"] = (inner, 2, 39, 1)
+        s[q + "conv.norm2.weight"] = (inner,)
+        s[q + "conv.norm2.bias"] = (inner,)
+        s[q + "conv.prelu2.weight"] = (inner,)
+        s[p + "norm2.weight"] = (inner,)
+        s[p + "norm2.bias"] = (inner,)
+        s[p + "conv2.weight"] = (d, inner, 1)
+        s[p + "conv2.bias"] = (d,)
+    for l in range(num_blocks):
+        p = f"{_PFX}layers.{l}."
+        s[p + "rotary_pos_emb.freqs"] = (rot_dim // 2,)
+        for nm, (i, o) in (("to_hidden", (d, hid)), ("to_qk", (d, qk_dim))):
+            s[p + nm + ".mdl.0.g"] = (1,)
+            s[p + nm + ".mdl.1.weight"] = (o, i)
+            s[p + nm + ".mdl.1.bias"] = (o,)
+            s[p + nm + ".mdl.3.sequential.1.conv.weight"] = (o, 1, 17)
+        s[p + "qk_offset_scale.gamma"] = (4, qk_dim)
+        s[p + "qk_offset_scale.beta"] = (4, qk_dim)
+        s[p + "to_out.mdl.0.g"] = (1,)
+        s[p + "to_out.mdl.1.weight"] = (d, 2 * d)
+        s[p + "to_out.mdl.1.bias"] = (d,)
+        s[p + "to_out.mdl.3.sequential.1.conv.weight"] = (d, 1, 17)
+    s["mask_net.mdl.intra_mdl.norm.weight"] = (d,)
+    s["mask_net.mdl.intra_mdl.norm.bias"] = (d,)
+    s["mask_net.mdl.intra_norm.weight"] = (d,)
+    s["mask_net.mdl.intra_norm.bias"] = (d,)
+    s["mask_net.conv1d_out.weight"] = (d * num_spks, d, 1)
+    s["mask_net.conv1d_out.bias"] = (d * num_spks,)
+    s["mask_net.conv1_decoder.weight"] = (d, d, 1)
+    s["mask_net.prelu.weight"] = (1,)
+    s["mask_net.output.0.weight"] = (d, d, 1)
+    s["mask_net.output.0.bias"] = (d,)
+    s["mask_net.output_gate.0.weight"] = (d, d, 1)
+    s["mask_net.output_gate.0.bias"] = (d,)
+    s["dec.weight"] = (d, 1, kernel_size)
+    return s
+
+
+def philox_uniform(name: str, n: int, seed: int = 0) -> np.ndarray:
+    """n float32 values in [-1, 1): top 24 bits of Philox4x64 raw words, keyed by
+    (seed, crc32(name)).  `random_raw` is the documented stable bit stream."""
+    key = np.array([seed & 0xFFFFFFFFFFFFFFFF, zlib.crc32(name.encode())], dtype=np.uint64)
+    raw = np.random.Philox(key=key).random_raw(n)
+    f = (raw >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / (1 << 24))
+    return (f * np.float32(2.0) - np.float32(1.0)).astype(np.float32)
+
+
+def _recipe_tensor(name: str, shape: tuple, seed: int) -> torch.Tensor:
+    n = int(np.prod(shape))
+    if name.endswith("pos_enc.inv_freq"):
+        dim = shape[0] * 2
+        return 1.0 / (10000 ** (torch.arange(0, dim, 2).float() / dim))
+    if name.endswith("rotary_pos_emb.freqs"):
+        dim = shape[0] * 2
+        return 1.0 / (10000 ** (torch.arange(0, dim, 2).float() / dim))
+    u = torch.from_numpy(philox_uniform(name, n, seed)).reshape(shape)
+    leaf = name.rsplit(".", 1)[-1]
+    is_norm = any(t in name for t in (".norm.", ".norm1.", ".norm2.", "intra_norm.", ".mdl.0.weight", ".mdl.0.bias"))
+    if name.endswith(".g") or name.endswith("pos_enc.scale"):
+        return 1.0 + 0.2 * u
+    if "prelu" in name or name.endswith("conv1.1.weight"):
+        return 0.25 + 0.1 * u
+    if name.endswith("qk_offset_scale.gamma"):
+        return 2.5 + 1.0 * u      # large enough that the relu^2 quadratic branch matters
+    if name.endswith("qk_offset_scale.beta"):
+        return 0.3 * u
+    if is_norm:
+        return (1.0 + 0.2 * u) if leaf == "weight" else (0.1 * u)
+    if leaf == "bias":
+        return 0.1 * u
+    fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
+    return u * float(1.0 / np.sqrt(fan_in))
+
+
+def recipe_state_dict(seed: int = 0, num_blocks: int = 24, **kw) -> "OrderedDict[str, torch.Tensor]":
+    """Deterministic fp32 weights for the MossFormer2 layout (see module docstring)."""
+    out = OrderedDict()
+    for name, shape in mossformer2_param_shapes(num_blocks=num_blocks, **kw).items():
+        # the reference shares ONE RotaryEmbedding across layers -> identical tensors
+        out[name] = _recipe_tensor(name, shape, seed).to(torch.float32).contiguous()
+    return out
+
+
+def recipe_wave(name: str, batch: int, n: int, seed: int = 0, amp: float = 0.1) -> np.ndarray:
+    """Deterministic synthetic input waveforms [batch, n] float32 in [-amp, amp)."""
+    return (philox_uniform(f"wave:{name}", batch * n, seed) * np.float32(amp)).reshape(batch, n)
+
+
+# ---------------------------------------------------------------------------------------
+# TDXW blob: magic(8) | u32 n | n x { u16 name_len | name | u8 ndim | u32 dims[ndim] |
+#            u64 data_offset (bytes from start of data section) } | pad to 64 | data (f32 LE)
+# ---------------------------------------------------------------------------------------
+TDXW_MAGIC = b"TDXW0001"
+
+
+def pack_blob(state_dict) -> bytes:
+    head = bytearray()
+    head += TDXW_MAGIC
+    items = [(k, v) for k, v in state_dict.items()]
+    head += struct.pack("<I", len(items))
+    datas = []
+    off = 0
+    for k, v in items:
+        a = np.ascontiguousarray(v.detach().cpu().to(torch.float32).numpy() if isinstance(v, torch.Tensor)
+                                 else np.asarray(v, dtype=np.float32))
+        kb = k.encode()
+        head += struct.pack("<H", len(kb)) + kb
+        head += struct.pack("<B", a.ndim)
+        for dim in a.shape:
+            head += struct.pack("<I", dim)
+        head += struct.pack("<Q", off)
+        datas.append(a.tobytes())
+        off += (a.nbytes + 63) // 64 * 64
+    pad = (-len(head)) % 64
+    head += b"\0" * pad
+    body = bytearray()
+    for dbytes in datas:
+        body += dbytes
+        body += b"\0" * ((-len(dbytes)) % 64)
+    return bytes(head) + bytes(body)

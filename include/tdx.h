@@ -1,0 +1,112 @@
+/* tdx.h — C-ABI of the MI355X-native TargetDiarization hot path (libtdx.so).
+ *
+ * The reference (ishine/TargetDiarization) is pure Python and has no FFI; its "plugin
+ * boundary" for this path is four Python call sites.  Each entry point below replaces one
+ * of them (reference file:line cited per function).  The Python host in
+ * targetdiarization_amd/ binds these with ctypes (see INTEGRATION.md for the stub a
+ * reference maintainer would add).
+ *
+ * Conventions
+ *  - plain C types only; every pointer named *_dev is a DEVICE pointer owned by the caller
+ *    (PyTorch-ROCm allocates; `tensor.data_ptr()`), every stream is a hipStream_t passed
+ *    as void*.  The library owns only the opaque model handle (weights + tables).
+ *  - every function returns 0 on success, non-zero TDX_E_* otherwise; no C++ exception
+ *    crosses the boundary; tdx_last_error() returns a thread-local message.
+ *  - all launches are asynchronous on the given stream; no hipMalloc/hipFree/sync inside
+ *    a forward call (graph-capture safe).  Handles are re-entrant per (handle, workspace,
+ *    stream) triple: no global mutable state.
+ */
+#ifndef TDX_H
+#define TDX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDX_OK 0
+#define TDX_E_INVALID 1   /* bad argument / shape */
+#define TDX_E_BLOB 2      /* weight blob malformed or tensor missing */
+#define TDX_E_HIP 3       /* HIP runtime error */
+#define TDX_E_WORKSPACE 4 /* workspace too small */
+
+/* library version string, e.g. "tdx 0.1.0 gfx950" */
+const char* tdx_version(void);
+/* thread-local description of the last non-zero status returned on this thread */
+const char* tdx_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * H1  MossFormer2 separator — replaces `self.separater(audio_data_tensor)`
+ *     AudioProcessor.py:943  (model: look2hear/models/mossformer2.py:563-589)
+ *     loader replaces BaseModel.from_pretrain  base_model.py:52-64
+ * ---------------------------------------------------------------------------------- */
+typedef struct tdx_mf2 tdx_mf2;
+
+typedef struct tdx_mf2_config {
+    int32_t num_blocks;   /* 24  (mossformer2.py:535) */
+    int32_t channels;     /* 512 (in_channels == out_channels, :533-534); must be 512 */
+    int32_t kernel_size;  /* 16  (:536), stride = kernel_size/2 */
+    int32_t num_spks;     /* 2   (:538); must be 2 */
+    int32_t group_size;   /* 256 (mossformer_block.py:434) */
+    int32_t reserved[3];
+} tdx_mf2_config;
+
+/* weights_blob: host memory in the TDXW container (targetdiarization_amd/weights.py:pack_blob)
+ * holding the reference's state_dict tensors under their reference names. */
+int tdx_mf2_create(const tdx_mf2_config* cfg, const void* weights_blob, size_t blob_bytes,
+                   int device, tdx_mf2** out);
+int tdx_mf2_destroy(tdx_mf2* h);
+/* bytes of device workspace tdx_mf2_forward needs for a [B,T] batch (0 on bad shape) */
+size_t tdx_mf2_workspace_bytes(const tdx_mf2* h, int B, int T);
+/* wav_dev [B,T] f32 -> out_dev [B,2,T] f32.  All B windows must have the same T (the
+ * reference never pads a batch: mossformer_block.py:485 passes no mask). */
+int tdx_mf2_forward(tdx_mf2* h, const float* wav_dev, int B, int T, float* out_dev,
+                    void* workspace_dev, size_t workspace_bytes, void* stream);
+/* algorithmic FLOPs (2*MAC) of one forward at [B,T] — SURVEY.md §8(d) accounting */
+double tdx_mf2_flops(const tdx_mf2* h, int B, int T);
+
+/* test/diagnostic tap: copy a named intermediate of the LAST forward on (h, workspace)
+ * into dst_dev (f32).  names: "enc","z","after_flash0","after_fsmn0","after_stack","mask".
+ * Layouts are token-major ([B,S,C]; "mask" is [2,B,S,C]).  Returns element count via *n. */
+int tdx_mf2_tap(tdx_mf2* h, const char* name, int B, int T, void* workspace_dev,
+                float* dst_dev, size_t dst_elems, size_t* n, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Stand-alone ops exported for parity tests of individual reference functions
+ * ---------------------------------------------------------------------------------- */
+/* FLASH_ShareA_FFConvM.cal_attention (mossformer_block.py:222-294), non-causal, no mask.
+ * q/k inputs [B,S,128] are the four OffsetScale heads BEFORE rotary; v,u [B,S,E], E%64==0.
+ * freqs_dev: 16 rotary frequencies.  att_v/att_u out [B,S,E]. */
+int tdx_cal_attention(const float* quad_q_dev, const float* lin_q_dev, const float* quad_k_dev,
+                      const float* lin_k_dev, const float* v_dev, const float* u_dev,
+                      const float* freqs_dev, int B, int S, int E, float* att_v_dev,
+                      float* att_u_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+size_t tdx_cal_attention_workspace_bytes(int B, int S, int E);
+
+/* DilatedDenseNet.forward (fsmn.py:103-111) on token-major p[B,S,256] -> out[B,S,256].
+ * w1[256,39], w2[256,2,39], in_g/in_b[2,256] (InstanceNorm affine), prelu[2,256]. */
+int tdx_dilated_dense_net(const float* p_dev, int B, int S, const float* w1_dev,
+                          const float* w2_dev, const float* in_g_dev, const float* in_b_dev,
+                          const float* prelu_dev, float* out_dev, void* workspace_dev,
+                          size_t workspace_bytes, void* stream);
+size_t tdx_dilated_dense_net_workspace_bytes(int B, int S);
+
+/* C[M,N] = A[M,K] * W[N,K]^T (+bias[N]); fp32 MFMA; N%128==0, K%32==0.  Test hook for the
+ * GEMM core every nn.Linear / 1x1 Conv1d on the path goes through. */
+int tdx_linear(const float* a_dev, const float* w_dev, const float* bias_dev, int M, int N, int K,
+               float* c_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * a11  cosine scoring — replaces TargetASR.cosine_similarity  TargetASR.py:144-152
+ *      emb_dev [N,D] f32, ref_dev [D] f32 -> scores_dev [N] f32 (1.0 if either vector is
+ *      all-zero, else cos clipped to [0,1]).
+ * ---------------------------------------------------------------------------------- */
+int tdx_cosine_scores(const float* emb_dev, const float* ref_dev, int N, int D, float* scores_dev,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDX_H */

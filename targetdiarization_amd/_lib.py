@@ -1,0 +1,62 @@
+"""ctypes binding of libtdx.so (include/tdx.h).  Fails loudly when the library is missing:
+there is no CPU / PyTorch fallback anywhere in the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtdx.so")
+
+
+class TdxError(RuntimeError):
+    pass
+
+
+class Mf2Config(C.Structure):
+    _fields_ = [("num_blocks", C.c_int32), ("channels", C.c_int32), ("kernel_size", C.c_int32),
+                ("num_spks", C.c_int32), ("group_size", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+_lib = None
+
+# every symbol include/tdx.h declares: (restype, argtypes)
+_vp, _sz, _i, _fp = C.c_void_p, C.c_size_t, C.c_int, C.c_void_p
+SIGNATURES = {
+    "tdx_version": (C.c_char_p, []),
+    "tdx_last_error": (C.c_char_p, []),
+    "tdx_mf2_create": (_i, [C.POINTER(Mf2Config), _vp, _sz, _i, C.POINTER(_vp)]),
+    "tdx_mf2_destroy": (_i, [_vp]),
+    "tdx_mf2_enable_taps": (_i, [_vp, _i]),
+    "tdx_mf2_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "tdx_mf2_forward": (_i, [_vp, _fp, _i, _i, _fp, _vp, _sz, _vp]),
+    "tdx_mf2_flops": (C.c_double, [_vp, _i, _i]),
+    "tdx_mf2_tap": (_i, [_vp, C.c_char_p, _i, _i, _vp, _fp, _sz, C.POINTER(_sz), _vp]),
+    "tdx_cal_attention": (_i, [_fp] * 7 + [_i, _i, _i, _fp, _fp, _vp, _sz, _vp]),
+    "tdx_cal_attention_workspace_bytes": (_sz, [_i, _i, _i]),
+    "tdx_dilated_dense_net": (_i, [_fp, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),
+    "tdx_dilated_dense_net_workspace_bytes": (_sz, [_i, _i]),
+    "tdx_linear": (_i, [_fp, _fp, _fp, _i, _i, _i, _fp, _vp]),
+    "tdx_cosine_scores": (_i, [_fp, _fp, _i, _i, _fp, _vp]),
+}
+
+
+def lib():
+    """Load libtdx.so once; raise TdxError if it is absent (never fall back)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TdxError(f"{LIB_PATH} not found: build it with `python -m targetdiarization_amd.build` "
+                           "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(status: int):
+    if status != 0:
+        raise TdxError(f"libtdx status {status}: {lib().tdx_last_error().decode()}")

@@ -1,0 +1,584 @@
+// mf2_kernels.hpp — the HBM-bound kernels of the MossFormer2 path (everything that is not a
+// GEMM): encoder/decoder strided convs, norms (ScaleNorm row scales, LayerNorm, GroupNorm,
+// InstanceNorm statistics), depthwise convs (k=17, k=39 dilated), offset-scale + rotary.
+// All tensors are token-major fp32 ([B,S,C] with C contiguous) so that one wave reads
+// whole 1-4 KB rows with 16 B per lane.  Reference lines are cited at each kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tdx {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float siluf_acc(float x) { return x / (1.0f + expf(-x)); }
+
+// ---------------------------------------------------------------------------------------
+// Encoder: E[b,s,c] = relu(sum_t w[c,t] * wav[b, 8s+t])   (mossformer2.py:157-210)
+// block = 128 threads (one channel quad each), TOK tokens per block; also emits per-block
+// partial (sum, sumsq) in double for the GroupNorm(1,512) that follows (mossformer2.py:487).
+// wT is [16][512] (tap-major).
+// ---------------------------------------------------------------------------------------
+constexpr int ENC_TOK = 32;
+__global__ __launch_bounds__(128) void encoder_kernel(const float* __restrict__ wav, const float* __restrict__ wT,
+                                                       float* __restrict__ E, double* __restrict__ part, int T, int S,
+                                                       int nblk) {
+    __shared__ float seg[8 * ENC_TOK + 8];
+    __shared__ double red[2][2];
+    const int b = blockIdx.y, s0 = blockIdx.x * ENC_TOK, tid = threadIdx.x;
+    const float* wv = wav + (long)b * T;
+    for (int i = tid; i < 8 * ENC_TOK + 8; i += 128) {
+        const int t = 8 * s0 + i;
+        seg[i] = t < T ? wv[t] : 0.f;
+    }
+    float4 w[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) w[t] = *reinterpret_cast<const float4*>(wT + t * 512 + tid * 4);
+    __syncthreads();
+    double sum = 0.0, sq = 0.0;
+    const int ns = min(ENC_TOK, S - s0);
+    for (int i = 0; i < ns; ++i) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float x = seg[8 * i + t];
+            a.x = fmaf(w[t].x, x, a.x); a.y = fmaf(w[t].y, x, a.y);
+            a.z = fmaf(w[t].z, x, a.z); a.w = fmaf(w[t].w, x, a.w);
+        }
+        a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+        *reinterpret_cast<float4*>(E + ((long)b * S + s0 + i) * 512 + tid * 4) = a;
+        const float ps = (a.x + a.y) + (a.z + a.w);
+        const float pq = (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+        sum += (double)ps; sq += (double)pq;
+    }
+    sum = wave_sum_d(sum); sq = wave_sum_d(sq);
+    if ((tid & 63) == 0) { red[tid >> 6][0] = sum; red[tid >> 6][1] = sq; }
+    __syncthreads();
+    if (tid == 0) {
+        part[((long)b * nblk + blockIdx.x) * 2 + 0] = red[0][0] + red[1][0];
+        part[((long)b * nblk + blockIdx.x) * 2 + 1] = red[0][1] + red[1][1];
+    }
+}
+
+// per-sample partial (sum,sumsq) of a [B,S,512] tensor: one block per (chunk, b)
+__global__ __launch_bounds__(256) void rowblock_stats_kernel(const float* __restrict__ x, double* __restrict__ part,
+                                                              int S, int rows_per_blk, int nblk) {
+    __shared__ double red[4][2];
+    const int b = blockIdx.y, r0 = blockIdx.x * rows_per_blk, tid = threadIdx.x;
+    const int r1 = min(S, r0 + rows_per_blk);
+    double sum = 0.0, sq = 0.0;
+    for (int r = r0 + (tid >> 7); r < r1; r += 2) {
+        const float4 a = *reinterpret_cast<const float4*>(x + ((long)b * S + r) * 512 + (tid & 127) * 4);
+        sum += (double)((a.x + a.y) + (a.z + a.w));
+        sq += (double)((a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w));
+    }
+    sum = wave_sum_d(sum); sq = wave_sum_d(sq);
+    if ((tid & 63) == 0) { red[tid >> 6][0] = sum; red[tid >> 6][1] = sq; }
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0, q = 0;
+        for (int i = 0; i < 4; ++i) { s += red[i][0]; q += red[i][1]; }
+        part[((long)b * nblk + blockIdx.x) * 2 + 0] = s;
+        part[((long)b * nblk + blockIdx.x) * 2 + 1] = q;
+    }
+}
+
+// finalize GroupNorm(1,C) statistics: stat[b] = (mean, rstd), biased variance over n elems
+__global__ void gn_finalize_kernel(const double* __restrict__ part, float* __restrict__ stat, int nblk, double n,
+                                   double eps) {
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) {
+        double s = 0, q = 0;
+        for (int i = 0; i < nblk; ++i) { s += part[((long)b * nblk + i) * 2]; q += part[((long)b * nblk + i) * 2 + 1]; }
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        if (var < 0) var = 0;
+        stat[b * 2 + 0] = (float)mean;
+        stat[b * 2 + 1] = (float)(1.0 / sqrt(var + eps));
+    }
+}
+
+// y[m,c] = (x[m,c]-mean_b)*rstd_b*gamma[c]+beta[c] (+ skip[m,c]) (PReLU scalar a)   [M,512]
+// MODE 0: plain GroupNorm apply (mossformer2.py:487)
+// MODE 1: GroupNorm apply + skip + PReLU(1)  (mossformer2.py:389-396, :500)
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stat,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ skip, const float* __restrict__ prelu,
+                                                        float* __restrict__ y, long M, int S) {
+    const long i4 = (long)blockIdx.x * 256 + threadIdx.x;   // float4 index
+    if (i4 >= M * 128) return;
+    const long m = i4 >> 7;
+    const int c = (int)(i4 & 127) * 4;
+    const int b = (int)(m / S);
+    const float mean = stat[b * 2], rstd = stat[b * 2 + 1];
+    const float4 a = *reinterpret_cast<const float4*>(x + i4 * 4);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 be = *reinterpret_cast<const float4*>(beta + c);
+    float4 o;
+    o.x = (a.x - mean) * rstd * g.x + be.x; o.y = (a.y - mean) * rstd * g.y + be.y;
+    o.z = (a.z - mean) * rstd * g.z + be.z; o.w = (a.w - mean) * rstd * g.w + be.w;
+    if (MODE == 1) {
+        const float4 sk = *reinterpret_cast<const float4*>(skip + i4 * 4);
+        const float al = prelu[0];
+        o.x += sk.x; o.y += sk.y; o.z += sk.z; o.w += sk.w;
+        o.x = o.x >= 0.f ? o.x : al * o.x; o.y = o.y >= 0.f ? o.y : al * o.y;
+        o.z = o.z >= 0.f ? o.z : al * o.z; o.w = o.w >= 0.f ? o.w : al * o.w;
+    }
+    *reinterpret_cast<float4*>(y + i4 * 4) = o;
+}
+
+// ---------------------------------------------------------------------------------------
+// ScaleNorm row scale: rs[m] = 1 / max(||row||_2 * C^-0.5, 1e-5)  (mossformer_block.py:44-54)
+// SHIFT: the row is the token-shifted one (first C/2 channels from token s-1, zero at s=0;
+// mossformer_block.py:204-207).  One wave per row; C = 512 or 1024.
+// ---------------------------------------------------------------------------------------
+template <int C, bool SHIFT>
+__global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__ x, float* __restrict__ rs, long M, int S) {
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int lane = threadIdx.x & 63;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < C / 256; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        long row = m;
+        bool ok = true;
+        if (SHIFT && c < C / 2) { ok = (m % S) != 0; row = m - 1; }
+        if (ok) {
+            const float4 a = *reinterpret_cast<const float4*>(x + row * C + c);
+            acc += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        const float nrm = sqrtf(acc) * (C == 512 ? 0.044194173824159216f : 0.03125f);
+        rs[m] = 1.0f / fmaxf(nrm, 1e-5f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm over C channels of each row, one wave per row (C = 256 or 512).
+//   out1 = LN(x)*g1+b1 ;  DUAL: out2 = LN_noaffine(out1)  (the affine of the following
+//   FFConvM LayerNorm is folded into its Linear on the host).
+// CLayerNorm layer_norm.py:9-30 (eps 1e-5); final LayerNorm mossformer2.py:307,320 (eps 1e-6)
+// ---------------------------------------------------------------------------------------
+template <int C, bool DUAL>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g1,
+                                                         const float* __restrict__ b1, float* __restrict__ out1,
+                                                         float* __restrict__ out2, long M, float eps) {
+    constexpr int NV = C / 256;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int lane = threadIdx.x & 63;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = *reinterpret_cast<const float4*>(x + m * C + (i * 64 + lane) * 4);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + eps);
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        const float4 g = *reinterpret_cast<const float4*>(g1 + c);
+        const float4 b = *reinterpret_cast<const float4*>(b1 + c);
+        v[i].x = v[i].x * rstd * g.x + b.x; v[i].y = v[i].y * rstd * g.y + b.y;
+        v[i].z = v[i].z * rstd * g.z + b.z; v[i].w = v[i].w * rstd * g.w + b.w;
+        *reinterpret_cast<float4*>(out1 + m * C + c) = v[i];
+        s2 += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    if (DUAL) {
+        const float mean2 = wave_sum(s2) * (1.0f / C);
+        float q2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i].x -= mean2; v[i].y -= mean2; v[i].z -= mean2; v[i].w -= mean2;
+            q2 += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+        const float rstd2 = 1.0f / sqrtf(wave_sum(q2) * (1.0f / C) + eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i].x *= rstd2; v[i].y *= rstd2; v[i].z *= rstd2; v[i].w *= rstd2;
+            *reinterpret_cast<float4*>(out2 + m * C + (i * 64 + lane) * 4) = v[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Depthwise conv k=17 'same' along tokens + identity:  out = y + dwconv17(y)
+// (ConvModule conv_module.py:180-220).  Thread = one channel quad, walks TPT tokens with a
+// register sliding window; block = (QB quads, TY token groups).  wT is [17][C] tap-major.
+//   MODE 0: out[m, c] = val                                   (to_hidden -> v|u ; to_u|to_v)
+//   MODE 1: x[m, c] += val                                    (to_out branch + residual, :219)
+//   MODE 2: four OffsetScale heads + rotary (mossformer_block.py:76-86, :230-233) written to
+//           qk4[h][b][Sp][128]; rows S..Sp-1 are written as zeros (group padding, :238-241).
+// ---------------------------------------------------------------------------------------
+struct Conv17Args {
+    const float* in; long ld_in; int col0;   // input rows [B*S, ld_in], channel offset col0
+    const float* wT; int C;                  // weights [17][C]
+    float* out; long ld_out;                 // MODE 0/1
+    int S, Sp;
+    // MODE 2
+    const float* gamma; const float* beta;   // [4][128]
+    const float* rot_cos; const float* rot_sin;  // [S][16]
+    float* qk4; long head_stride;            // B*Sp*128
+};
+
+template <int MODE, int TPT>
+__global__ __launch_bounds__(256) void conv17_kernel(Conv17Args a) {
+    constexpr int U = 4, W = 16 + U;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;      // channel quad
+    const int c = q * 4;
+    const int b = blockIdx.z;
+    const int s_begin = (blockIdx.y * blockDim.y + threadIdx.y) * TPT;
+    const int s_lim = MODE == 2 ? a.Sp : a.S;
+    if (c >= a.C || s_begin >= s_lim) return;
+    const int s_end = min(s_begin + TPT, s_lim);
+    const float* in = a.in + (long)b * a.S * a.ld_in + a.col0 + c;
+    float4 w[17];
+#pragma unroll
+    for (int t = 0; t < 17; ++t) w[t] = *reinterpret_cast<const float4*>(a.wT + (long)t * a.C + c);
+    auto ld = [&](int s) -> float4 {
+        return (s >= 0 && s < a.S) ? *reinterpret_cast<const float4*>(in + (long)s * a.ld_in)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    float4 win[W];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) win[i] = ld(s_begin - 8 + i);
+    for (int s0 = s_begin; s0 < s_end; s0 += U) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) win[16 + i] = ld(s0 + 8 + i);
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const int s = s0 + i;
+            float4 o = win[8 + i];
+#pragma unroll
+            for (int t = 0; t < 17; ++t) {
+                o.x = fmaf(w[t].x, win[i + t].x, o.x); o.y = fmaf(w[t].y, win[i + t].y, o.y);
+                o.z = fmaf(w[t].z, win[i + t].z, o.z); o.w = fmaf(w[t].w, win[i + t].w, o.w);
+            }
+            if (s < s_end) {
+                if (MODE == 0) {
+                    *reinterpret_cast<float4*>(a.out + ((long)b * a.S + s) * a.ld_out + c) = o;
+                } else if (MODE == 1) {
+                    float4* p = reinterpret_cast<float4*>(a.out + ((long)b * a.S + s) * a.ld_out + c);
+                    float4 x = *p;
+                    x.x += o.x; x.y += o.y; x.z += o.z; x.w += o.w;
+                    *p = x;
+                } else {
+                    const bool valid = s < a.S;
+                    float cs0 = 1.f, sn0 = 0.f, cs1 = 1.f, sn1 = 0.f;
+                    if (valid && c < 32) {
+                        cs0 = a.rot_cos[s * 16 + (c >> 1)]; sn0 = a.rot_sin[s * 16 + (c >> 1)];
+                        cs1 = a.rot_cos[s * 16 + (c >> 1) + 1]; sn1 = a.rot_sin[s * 16 + (c >> 1) + 1];
+                    }
+#pragma unroll
+                    for (int hh = 0; hh < 4; ++hh) {
+                        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (valid) {
+                            const float4 g = *reinterpret_cast<const float4*>(a.gamma + hh * 128 + c);
+                            const float4 be = *reinterpret_cast<const float4*>(a.beta + hh * 128 + c);
+                            float4 t4;
+                            t4.x = o.x * g.x + be.x; t4.y = o.y * g.y + be.y;
+                            t4.z = o.z * g.z + be.z; t4.w = o.w * g.w + be.w;
+                            if (c < 32) {
+                                r.x = t4.x * cs0 - t4.y * sn0; r.y = t4.y * cs0 + t4.x * sn0;
+                                r.z = t4.z * cs1 - t4.w * sn1; r.w = t4.w * cs1 + t4.z * sn1;
+                            } else {
+                                r = t4;
+                            }
+                        }
+                        *reinterpret_cast<float4*>(a.qk4 + hh * a.head_stride + ((long)b * a.Sp + s) * 128 + c) = r;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) win[i] = win[i + U];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// DilatedDenseNet (fsmn.py:76-111), token-major, one thread per channel, 256 threads.
+//  conv1: c1 = dwconv_{k=39,dil=1,pad=19}(p)                         (+ IN statistics)
+//  conv2: c2[j] = sum_t w2[j,0,t]*cat[2j][s+2t-38] + w2[j,1,t]*cat[2j+1][s+2t-38]
+//         cat = [prelu(IN(c1)) (256 ch), p (256 ch)]                   (+ IN statistics)
+// Statistics: per (b, chunk, channel) partial (sum, sumsq) in double -> in_finalize_kernel.
+// w1T [39][256]; w2T [39][2][256].
+// ---------------------------------------------------------------------------------------
+constexpr int DDN_TS = 256;   // tokens per block (conv1) ; conv2 handles DDN_TS tokens of one parity
+__global__ __launch_bounds__(256) void ddn_conv1_kernel(const float* __restrict__ p, const float* __restrict__ w1T,
+                                                         float* __restrict__ c1, double* __restrict__ part, int S,
+                                                         int nchunk) {
+    constexpr int K = 39, U = 8, W = K - 1 + U;
+    const int ch = threadIdx.x, b = blockIdx.y, s_begin = blockIdx.x * DDN_TS;
+    const int s_end = min(s_begin + DDN_TS, S);
+    const float* in = p + (long)b * S * 256 + ch;
+    float w[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) w[t] = w1T[t * 256 + ch];
+    auto ld = [&](int s) -> float { return (s >= 0 && s < S) ? in[(long)s * 256] : 0.f; };
+    float win[W];
+#pragma unroll
+    for (int i = 0; i < K - 1; ++i) win[i] = ld(s_begin - 19 + i);
+    double sum = 0.0, sq = 0.0;
+    for (int s0 = s_begin; s0 < s_end; s0 += U) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) win[K - 1 + i] = ld(s0 + 19 + i);
+        float ps = 0.f, pq = 0.f;
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            float o = 0.f;
+#pragma unroll
+            for (int t = 0; t < K; ++t) o = fmaf(w[t], win[i + t], o);
+            if (s0 + i < s_end) {
+                c1[((long)b * S + s0 + i) * 256 + ch] = o;
+                ps += o; pq = fmaf(o, o, pq);
+            }
+        }
+        sum += (double)ps; sq += (double)pq;
+#pragma unroll
+        for (int i = 0; i < K - 1; ++i) win[i] = win[i + U];
+    }
+    part[(((long)b * nchunk + blockIdx.x) * 256 + ch) * 2 + 0] = sum;
+    part[(((long)b * nchunk + blockIdx.x) * 256 + ch) * 2 + 1] = sq;
+}
+
+// stat[b][c] = (mean, rstd) with biased variance over S tokens, eps 1e-5 (InstanceNorm2d)
+__global__ __launch_bounds__(256) void in_finalize_kernel(const double* __restrict__ part, float* __restrict__ stat,
+                                                           int nchunk, int S) {
+    const int b = blockIdx.x, ch = threadIdx.x;
+    double s = 0, q = 0;
+    for (int i = 0; i < nchunk; ++i) {
+        s += part[(((long)b * nchunk + i) * 256 + ch) * 2];
+        q += part[(((long)b * nchunk + i) * 256 + ch) * 2 + 1];
+    }
+    const double mean = s / S;
+    double var = q / S - mean * mean;
+    if (var < 0) var = 0;
+    stat[(b * 256 + ch) * 2 + 0] = (float)mean;
+    stat[(b * 256 + ch) * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
+}
+
+// conv2: blockIdx.x = chunk*2 + parity; thread j = output channel.
+__global__ __launch_bounds__(256) void ddn_conv2_kernel(const float* __restrict__ c1, const float* __restrict__ p,
+                                                         const float* __restrict__ stat1, const float* __restrict__ in_g,
+                                                         const float* __restrict__ in_b, const float* __restrict__ prelu,
+                                                         const float* __restrict__ w2T, float* __restrict__ c2,
+                                                         double* __restrict__ part, int S, int nchunk2) {
+    constexpr int K = 39, U = 4, W = K - 1 + U;
+    const int j = threadIdx.x, b = blockIdx.y;
+    const int par = blockIdx.x & 1, chunk = blockIdx.x >> 1;
+    // this block's outputs: tokens s = s_begin + 2*i (same parity), i in [0, DDN_TS)
+    const int s_begin = chunk * (2 * DDN_TS) + par;
+    const bool from_c1 = j < 128;
+    const int ic = from_c1 ? 2 * j : 2 * (j - 128);
+    const float* src = (from_c1 ? c1 : p) + (long)b * S * 256 + ic;
+    float mu0 = 0.f, rs0 = 1.f, g0 = 1.f, be0 = 0.f, al0 = 1.f, mu1 = 0.f, rs1 = 1.f, g1 = 1.f, be1 = 0.f, al1 = 1.f;
+    if (from_c1) {
+        mu0 = stat1[(b * 256 + ic) * 2]; rs0 = stat1[(b * 256 + ic) * 2 + 1];
+        mu1 = stat1[(b * 256 + ic + 1) * 2]; rs1 = stat1[(b * 256 + ic + 1) * 2 + 1];
+        g0 = in_g[ic]; be0 = in_b[ic]; al0 = prelu[ic];
+        g1 = in_g[ic + 1]; be1 = in_b[ic + 1]; al1 = prelu[ic + 1];
+    }
+    float w0[K], w1[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) { w0[t] = w2T[(t * 2 + 0) * 256 + j]; w1[t] = w2T[(t * 2 + 1) * 256 + j]; }
+    auto ld = [&](int s) -> float2 {
+        if (s < 0 || s >= S) return make_float2(0.f, 0.f);
+        float2 v = *reinterpret_cast<const float2*>(src + (long)s * 256);
+        if (from_c1) {
+            v.x = (v.x - mu0) * rs0 * g0 + be0; v.x = v.x >= 0.f ? v.x : al0 * v.x;
+            v.y = (v.y - mu1) * rs1 * g1 + be1; v.y = v.y >= 0.f ? v.y : al1 * v.y;
+        }
+        return v;
+    };
+    float2 win[W];
+#pragma unroll
+    for (int i = 0; i < K - 1; ++i) win[i] = ld(s_begin - 38 + 2 * i);
+    double sum = 0.0, sq = 0.0;
+    for (int i0 = 0; i0 < DDN_TS; i0 += U) {
+        if (s_begin + 2 * i0 >= S) break;
+#pragma unroll
+        for (int i = 0; i < U; ++i) win[K - 1 + i] = ld(s_begin + 2 * (i0 + i) + 38);
+        float ps = 0.f, pq = 0.f;
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            float o = 0.f;
+#pragma unroll
+            for (int t = 0; t < K; ++t) { o = fmaf(w0[t], win[i + t].x, o); o = fmaf(w1[t], win[i + t].y, o); }
+            const int s = s_begin + 2 * (i0 + i);
+            if (s < S) {
+                c2[((long)b * S + s) * 256 + j] = o;
+                ps += o; pq = fmaf(o, o, pq);
+            }
+        }
+        sum += (double)ps; sq += (double)pq;
+#pragma unroll
+        for (int i = 0; i < K - 1; ++i) win[i] = win[i + U];
+    }
+    part[(((long)b * nchunk2 + blockIdx.x) * 256 + j) * 2 + 0] = sum;
+    part[(((long)b * nchunk2 + blockIdx.x) * 256 + j) * 2 + 1] = sq;
+}
+
+// out[m,c] = prelu(IN(c2))   (stand-alone DilatedDenseNet output, test hook)
+__global__ __launch_bounds__(256) void ddn_out_kernel(const float* __restrict__ c2, const float* __restrict__ stat2,
+                                                       const float* __restrict__ in_g, const float* __restrict__ in_b,
+                                                       const float* __restrict__ prelu, float* __restrict__ out, long M, int S) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * 256) return;
+    const int ch = (int)(i & 255);
+    const int b = (int)((i >> 8) / S);
+    float v = (c2[i] - stat2[(b * 256 + ch) * 2]) * stat2[(b * 256 + ch) * 2 + 1] * in_g[ch] + in_b[ch];
+    out[i] = v >= 0.f ? v : prelu[ch] * v;
+}
+
+// Gated FSMN tail (mossformer_block.py:323-324, :422-423; fsmn.py:144):
+//   o2 = prelu(IN(c2)); xu2 = xu + o2; g = xv*xu2 + h; gn = LN_256(g)*gamma+beta   one wave / row
+__global__ __launch_bounds__(256) void fsmn_tail_kernel(const float* __restrict__ c2, const float* __restrict__ stat2,
+                                                         const float* __restrict__ in_g, const float* __restrict__ in_b,
+                                                         const float* __restrict__ prelu, const float* __restrict__ uv,
+                                                         const float* __restrict__ hh, const float* __restrict__ ln_g,
+                                                         const float* __restrict__ ln_b, float* __restrict__ gn, long M, int S) {
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int lane = threadIdx.x & 63, c = lane * 4;
+    const int b = (int)(m / S);
+    const float4 cv = *reinterpret_cast<const float4*>(c2 + m * 256 + c);
+    const float4 xu = *reinterpret_cast<const float4*>(uv + m * 512 + c);
+    const float4 xv = *reinterpret_cast<const float4*>(uv + m * 512 + 256 + c);
+    const float4 h4 = *reinterpret_cast<const float4*>(hh + m * 256 + c);
+    const float* st = stat2 + (long)(b * 256 + c) * 2;
+    const float4 ig = *reinterpret_cast<const float4*>(in_g + c);
+    const float4 ib = *reinterpret_cast<const float4*>(in_b + c);
+    const float4 al = *reinterpret_cast<const float4*>(prelu + c);
+    float o[4] = {cv.x, cv.y, cv.z, cv.w};
+    const float igv[4] = {ig.x, ig.y, ig.z, ig.w}, ibv[4] = {ib.x, ib.y, ib.z, ib.w}, alv[4] = {al.x, al.y, al.z, al.w};
+    const float xuv[4] = {xu.x, xu.y, xu.z, xu.w}, xvv[4] = {xv.x, xv.y, xv.z, xv.w}, hv[4] = {h4.x, h4.y, h4.z, h4.w};
+    float g[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v = (o[i] - st[i * 2]) * st[i * 2 + 1] * igv[i] + ibv[i];
+        v = v >= 0.f ? v : alv[i] * v;
+        g[i] = xvv[i] * (xuv[i] + v) + hv[i];
+        s += g[i];
+    }
+    const float mean = wave_sum(s) * (1.0f / 256);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { g[i] -= mean; q = fmaf(g[i], g[i], q); }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / 256) + 1e-5f);
+    const float4 lg = *reinterpret_cast<const float4*>(ln_g + c);
+    const float4 lb = *reinterpret_cast<const float4*>(ln_b + c);
+    float4 r;
+    r.x = g[0] * rstd * lg.x + lb.x; r.y = g[1] * rstd * lg.y + lb.y;
+    r.z = g[2] * rstd * lg.z + lb.z; r.w = g[3] * rstd * lg.w + lb.w;
+    *reinterpret_cast<float4*>(gn + m * 256 + c) = r;
+}
+
+// Kvu[b][d][c] = (sum_sp slab[b][sp][d][c]) / S      (mossformer_block.py:286,289)
+__global__ __launch_bounds__(256) void kvu_reduce_kernel(const float* __restrict__ slab, float* __restrict__ kvu,
+                                                          int splits, long per, float S) {
+    const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i4 * 4 >= per) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int sp = 0; sp < splits; ++sp) {
+        const float4 v = *reinterpret_cast<const float4*>(slab + ((long)b * splits + sp) * per + i4 * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    acc.x /= S; acc.y /= S; acc.z /= S; acc.w /= S;
+    *reinterpret_cast<float4*>(kvu + (long)b * per + i4 * 4) = acc;
+}
+
+// ---------------------------------------------------------------------------------------
+// Decoder: ConvTranspose1d(512->1,k=16,s=8) per speaker (mossformer2.py:213-257, :579-589).
+//  D[z][m][t] = sum_c EM[z][m][c]*wdec[c][t]  (one wave per token row; wdT [16][512])
+//  out[b][k][tau] = D[k][b,s=tau/8][tau%8] + D[k][b,s-1][tau%8+8], zero-padded/trimmed to T
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void decoder_dot_kernel(const float* __restrict__ EM, const float* __restrict__ wdT,
+                                                           float* __restrict__ D, long rows) {
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float4 a0 = *reinterpret_cast<const float4*>(EM + m * 512 + lane * 4);
+    const float4 a1 = *reinterpret_cast<const float4*>(EM + m * 512 + 256 + lane * 4);
+    float d[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const float4 w0 = *reinterpret_cast<const float4*>(wdT + t * 512 + lane * 4);
+        const float4 w1 = *reinterpret_cast<const float4*>(wdT + t * 512 + 256 + lane * 4);
+        float v = a0.x * w0.x;
+        v = fmaf(a0.y, w0.y, v); v = fmaf(a0.z, w0.z, v); v = fmaf(a0.w, w0.w, v);
+        v = fmaf(a1.x, w1.x, v); v = fmaf(a1.y, w1.y, v); v = fmaf(a1.z, w1.z, v); v = fmaf(a1.w, w1.w, v);
+        d[t] = wave_sum(v);
+    }
+    if (lane < 16) {
+        float v = d[0];
+#pragma unroll
+        for (int t = 1; t < 16; ++t) v = (lane == t) ? d[t] : v;
+        D[m * 16 + lane] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void decoder_ola_kernel(const float* __restrict__ D, float* __restrict__ out, int B,
+                                                           int S, int T) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;   // over B*2*T
+    if (i >= (long)B * 2 * T) return;
+    const int tau = (int)(i % T);
+    const int k = (int)((i / T) & 1);
+    const int b = (int)(i / (2L * T));
+    const int s = tau >> 3, t = tau & 7;
+    const float* Dk = D + ((long)k * B + b) * S * 16;
+    float v = 0.f;
+    if (s < S) v += Dk[(long)s * 16 + t];
+    if (s >= 1 && s - 1 < S) v += Dk[(long)(s - 1) * 16 + t + 8];
+    out[i] = v;
+}
+
+// cosine scores (TargetASR.py:144-152): one wave per embedding row.
+__global__ __launch_bounds__(256) void cosine_kernel(const float* __restrict__ emb, const float* __restrict__ ref, int N,
+                                                      int D, float* __restrict__ out) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int lane = threadIdx.x & 63;
+    double dot = 0, na = 0, nb = 0;
+    int nza = 0, nzb = 0;
+    for (int i = lane; i < D; i += 64) {
+        const double a = emb[(long)n * D + i], b = ref[i];
+        dot += a * b; na += a * a; nb += b * b;
+        nza |= (a != 0.0); nzb |= (b != 0.0);
+    }
+    dot = wave_sum_d(dot); na = wave_sum_d(na); nb = wave_sum_d(nb);
+    const bool anya = __any(nza), anyb = __any(nzb);
+    if (lane == 0) {
+        double s = 1.0;
+        if (anya && anyb) {
+            s = dot / (sqrt(na) * sqrt(nb));
+            s = s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s);
+        }
+        out[n] = (float)s;
+    }
+}
+
+}  // namespace tdx

@@ -1,0 +1,57 @@
+"""Stand-alone device ops exported by libtdx.so (test hooks for individual reference functions
+and the cosine scorer).  All take/return CUDA(HIP) torch tensors; PyTorch only owns memory."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+def _st(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def linear(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """C = A W^T (+bias) through the fp32-MFMA GEMM core (tdx_linear)."""
+    a = a.contiguous().float(); w = w.contiguous().float()
+    M, K = a.shape; N = w.shape[0]
+    c = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    _lib.check(_lib.lib().tdx_linear(a.data_ptr(), w.data_ptr(), bias.contiguous().data_ptr() if bias is not None else None,
+                                     M, N, K, c.data_ptr(), _st(a)))
+    return c
+
+
+def cal_attention(quad_q, lin_q, quad_k, lin_k, v, u, freqs):
+    """mossformer_block.py:222-294 on device (tdx_cal_attention)."""
+    l = _lib.lib()
+    ts = [t.contiguous().float() for t in (quad_q, lin_q, quad_k, lin_k, v, u, freqs)]
+    B, S, E = ts[4].shape
+    nb = int(l.tdx_cal_attention_workspace_bytes(B, S, E))
+    if nb == 0:
+        raise _lib.TdxError("cal_attention: bad shape")
+    ws = torch.empty(nb, dtype=torch.uint8, device=v.device)
+    av = torch.empty(B, S, E, device=v.device); au = torch.empty(B, S, E, device=v.device)
+    _lib.check(l.tdx_cal_attention(*[t.data_ptr() for t in ts], B, S, E, av.data_ptr(), au.data_ptr(), ws.data_ptr(), nb, _st(v)))
+    return av, au
+
+
+def dilated_dense_net(p, w1, w2, in_g, in_b, prelu):
+    """fsmn.py:103-111 on device (tdx_dilated_dense_net).  p[B,S,256]; w1[256,39]; w2[256,2,39];
+    in_g/in_b/prelu [2,256]."""
+    l = _lib.lib()
+    ts = [t.contiguous().float() for t in (p, w1, w2, in_g, in_b, prelu)]
+    B, S, _ = ts[0].shape
+    nb = int(l.tdx_dilated_dense_net_workspace_bytes(B, S))
+    ws = torch.empty(nb, dtype=torch.uint8, device=p.device)
+    out = torch.empty(B, S, 256, device=p.device)
+    _lib.check(l.tdx_dilated_dense_net(ts[0].data_ptr(), B, S, *[t.data_ptr() for t in ts[1:]], out.data_ptr(), ws.data_ptr(), nb, _st(p)))
+    return out
+
+
+def cosine_scores(emb: torch.Tensor, ref: torch.Tensor) -> torch.Tensor:
+    """TargetASR.cosine_similarity (TargetASR.py:144-152) for N embeddings vs one reference."""
+    emb = emb.contiguous().float(); ref = ref.contiguous().float()
+    N, D = emb.shape
+    out = torch.empty(N, device=emb.device)
+    _lib.check(_lib.lib().tdx_cosine_scores(emb.data_ptr(), ref.data_ptr(), N, D, out.data_ptr(), _st(emb)))
+    return out

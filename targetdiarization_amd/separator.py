@@ -1,0 +1,104 @@
+"""MossFormer2 separator: Python host over the C-ABI (tdx_mf2_*).
+
+Mirrors the call surface the reference uses at AudioProcessor.py:268-274, 943:
+    sep = MossFormer2Separator.from_pretrain(path)      # BaseModel.from_pretrain base_model.py:52-64
+    out = sep(wave_tensor[B,T])                          # -> [B,2,T]   (mossformer2.py:563-589)
+PyTorch is used only for device memory and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .weights import pack_blob
+
+
+class MossFormer2Separator:
+    def __init__(self, state_dict, device="cuda:0", num_blocks: int | None = None):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.TdxError("MossFormer2Separator needs a HIP device (cuda:N); there is no CPU path")
+        if num_blocks is None:
+            num_blocks = 1 + max(int(k.split("layers.")[1].split(".")[0]) for k in state_dict if ".layers." in k)
+        self.num_blocks = num_blocks
+        self._l = _lib.lib()
+        blob = pack_blob(state_dict)
+        cfg = _lib.Mf2Config(num_blocks=num_blocks, channels=512, kernel_size=16, num_spks=2, group_size=256)
+        h = C.c_void_p()
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        with torch.cuda.device(idx):
+            _lib.check(self._l.tdx_mf2_create(C.byref(cfg), buf, len(blob), idx, C.byref(h)))
+        self._h = h
+        self._ws = None
+        self._taps = False
+
+    @classmethod
+    def from_pretrain(cls, path, device="cuda:0", **kw):
+        """Load a look2hear checkpoint dict {"model_name","state_dict",...} (base_model.py:56-63)."""
+        conf = torch.load(path, map_location="cpu")
+        sd = conf["state_dict"] if "state_dict" in conf else conf
+        return cls(sd, device=device)
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        if torch.device(device) != self.device:
+            raise _lib.TdxError("weights live on %s; re-create the separator for another device" % self.device)
+        return self
+
+    def enable_taps(self, on=True):
+        _lib.check(self._l.tdx_mf2_enable_taps(self._h, 1 if on else 0))
+        self._taps = on
+        self._ws = None
+
+    def workspace_bytes(self, B, T):
+        return int(self._l.tdx_mf2_workspace_bytes(self._h, B, T))
+
+    def flops(self, B, T):
+        return float(self._l.tdx_mf2_flops(self._h, B, T))
+
+    def _workspace(self, B, T):
+        need = self.workspace_bytes(B, T)
+        if need == 0:
+            raise _lib.TdxError(f"bad shape B={B} T={T}")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def __call__(self, wav: torch.Tensor) -> torch.Tensor:
+        if wav.ndim == 1:
+            wav = wav.unsqueeze(0)
+        if wav.ndim == 3:
+            wav = wav.squeeze(1)
+        wav = wav.to(self.device, torch.float32).contiguous()
+        B, T = wav.shape
+        ws = self._workspace(B, T)
+        out = torch.empty(B, 2, T, dtype=torch.float32, device=self.device)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._l.tdx_mf2_forward(self._h, wav.data_ptr(), B, T, out.data_ptr(), ws.data_ptr(), ws.numel(), st))
+        self._last = (B, T)
+        return out
+
+    forward = __call__
+
+    def tap(self, name: str) -> torch.Tensor:
+        B, T = self._last
+        S = (T - 16) // 8 + 1
+        n = (2 if name == "mask" else 1) * B * S * 512
+        dst = torch.empty(n, dtype=torch.float32, device=self.device)
+        cnt = C.c_size_t()
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._l.tdx_mf2_tap(self._h, name.encode(), B, T, self._ws.data_ptr(), dst.data_ptr(), n, C.byref(cnt), st))
+        return dst.view(2, B, S, 512) if name == "mask" else dst.view(B, S, 512)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._l.tdx_mf2_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path (BASELINE.json metric: real-time factor).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already
+resident in HBM.  Workload at N=1 = BASELINE.json configs[1]: MossFormer2 separation,
+batch of 32 synthetic 4 s / 16 kHz two-speaker mixtures (recipe of SURVEY.md §8d config 2),
+24-block model at the reference's constructor defaults, recipe (random-init) weights, fp32.
+N>1: every rank runs the same per-GPU workload on its own mixtures (independent units, weak
+scaling; no data-path collective in the separation-only configuration).
+
+Output: ONE JSON line on rank 0 (see the driver contract), plus
+  roofline     — dominant kernel (the to_hidden+to_qk fp32-MFMA GEMM, 24 launches/step):
+                 achieved = algorithmic FLOPs per launch / mean launch duration measured with
+                 HIP events recorded on the forward's stream inside the timed region.
+  cpu_baseline — the oracle (CPU restatement of the reference, pinned to it by
+                 tests/golden) timed on this host's cores on a bounded sample of the same
+                 workload (N=1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def synth_mixtures(batch: int, n: int, seed: int) -> np.ndarray:
+    """SURVEY.md §8d config-2 generator: s1+s2, s_k = 0.05*N(0,1) shaped by a 4 Hz
+    raised-cosine AM envelope with random phase, clipped to [-1,1], f32."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    t = np.arange(n, dtype=np.float64) / 16000.0
+    out = np.zeros((batch, n), dtype=np.float64)
+    for b in range(batch):
+        for _ in range(2):
+            ph = rng.uniform(0, 2 * np.pi)
+            env = 0.5 * (1.0 - np.cos(2 * np.pi * 4.0 * t + ph))
+            out[b] += 0.05 * rng.standard_normal(n) * env
+    return np.clip(out, -1.0, 1.0).astype(np.float32)
+
+
+def cpu_baseline(sd, wave_np, budget_windows: int):
+    """Time the oracle on the host cores over `budget_windows` windows of the workload."""
+    from oracle import mossformer2_oracle as orc          # checker / baseline leg only
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x = torch.from_numpy(wave_np[:1])
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        n_done = 0
+        for i in range(budget_windows):
+            orc.mossformer2_forward(torch.from_numpy(wave_np[i:i + 1]), sd)
+            n_done += 1
+            if time.perf_counter() - t0 > 25.0:
+                break
+        dt = time.perf_counter() - t0
+    secs = n_done * wave_np.shape[1] / 16000.0
+    return {"value": secs / dt, "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "sample": f"{n_done} x [1,{wave_np.shape[1]}] windows of the same synthetic batch, B=1 per call "
+                      f"(the reference's own batch size), oracle/mossformer2_oracle.py, torch CPU fp32, {dt:.1f}s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--seconds", type=float, default=4.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch.distributed as dist
+    use_dist = world > 1
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+
+    from targetdiarization_amd.separator import MossFormer2Separator
+    from targetdiarization_amd.weights import recipe_state_dict
+
+    B, T = args.batch, int(round(args.seconds * 16000))
+    sd = recipe_state_dict(seed=0, num_blocks=24)
+    sep = MossFormer2Separator(sd, device=dev)
+    wave_np = synth_mixtures(B, T, seed=2 + 1000 * rank)
+    wav = torch.from_numpy(wave_np).to(dev)           # resident in HBM before timing
+    S = (T - 16) // 8 + 1
+
+    for _ in range(args.warmup):
+        out = sep(wav)
+    torch.cuda.synchronize(dev)
+    sep.profile_enable(24 * args.steps)
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = sep(wav)
+    barrier()
+    dt = time.perf_counter() - t0
+    gemm_ms, gemm_launches = sep.profile_collect()
+    assert torch.isfinite(out).all()
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    audio_s_per_step = world * B * T / 16000.0
+    value = audio_s_per_step * args.steps / dt
+    flops_step = sep.flops(B, T)
+    if rank == 0:
+        M = B * S
+        gemm_flops = 2.0 * M * 512 * 2176          # to_hidden+to_qk: [M,512] x [512,2176]
+        ach = gemm_flops / (gemm_ms / max(gemm_launches, 1) * 1e-3) / 1e12 if gemm_launches else None
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get("gemm_to_hidden_hbm_bytes_per_launch")
+        line = {
+            "metric": "real-time factor (audio-sec/wall-sec), MossFormer2 separation, 16kHz mono",
+            "value": value, "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: MossFormer2 separation only, batch of {B} synthetic "
+                                   f"{args.seconds:g} s 16 kHz 2-speaker mixtures per GPU, 24 blocks, recipe weights",
+                       "per_gpu_batch": B, "samples_per_window": T, "frames_per_window": S,
+                       "parallelism": f"{world} independent replicas (windows sharded, no collective)"},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (ach / PEAK_F32_MFMA_TFLOPS) if ach else None, "traffic": traffic,
+                         "kernel": "gemm_f32_kernel<to_hidden+to_qk, token-shift A-load, ScaleNorm+SiLU epilogue>",
+                         "launches_timed": gemm_launches, "ms_per_launch": gemm_ms / max(gemm_launches, 1),
+                         "algorithmic_flops_per_launch": gemm_flops,
+                         "whole_path_tflops_per_gpu": flops_step * args.steps / dt / 1e12,
+                         "whole_path_frac": flops_step * args.steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS},
+            "algorithmic_flops_per_step_per_gpu": flops_step,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sd, wave_np, budget_windows=4)
+            line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

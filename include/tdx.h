@@ -67,6 +67,16 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav_dev, int B, int T, float* out_d
 /* algorithmic FLOPs (2*MAC) of one forward at [B,T] — SURVEY.md §8(d) accounting */
 double tdx_mf2_flops(const tdx_mf2* h, int B, int T);
 
+/* keep copies of the layer-0 intermediates and the mask for tdx_mf2_tap (costs workspace) */
+int tdx_mf2_enable_taps(tdx_mf2* h, int on);
+
+/* Live timing of the dominant kernel (the to_hidden+to_qk GEMM, one launch per block per
+ * forward): after enable, each forward records a HIP event pair around that launch on the
+ * forward's stream until max_records pairs are used; collect (after the caller synchronised
+ * the stream) returns the summed elapsed ms and the number of launches, and re-arms. */
+int tdx_mf2_profile_enable(tdx_mf2* h, int max_records);
+int tdx_mf2_profile_collect(tdx_mf2* h, double* total_ms, int* launches);
+
 /* test/diagnostic tap: copy a named intermediate of the LAST forward on (h, workspace)
  * into dst_dev (f32).  names: "enc","z","after_flash0","after_fsmn0","after_stack","mask".
  * Layouts are token-major ([B,S,C]; "mask" is [2,B,S,C]).  Returns element count via *n. */

@@ -28,6 +28,8 @@ SIGNATURES = {
     "tdx_mf2_create": (_i, [C.POINTER(Mf2Config), _vp, _sz, _i, C.POINTER(_vp)]),
     "tdx_mf2_destroy": (_i, [_vp]),
     "tdx_mf2_enable_taps": (_i, [_vp, _i]),
+    "tdx_mf2_profile_enable": (_i, [_vp, _i]),
+    "tdx_mf2_profile_collect": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),
     "tdx_mf2_workspace_bytes": (_sz, [_vp, _i, _i]),
     "tdx_mf2_forward": (_i, [_vp, _fp, _i, _i, _fp, _vp, _sz, _vp]),
     "tdx_mf2_flops": (C.c_double, [_vp, _i, _i]),
@@ -48,6 +50,15 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise TdxError(f"{LIB_PATH} not found: build it with `python -m targetdiarization_amd.build` "
                            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        # One HIP runtime per process: libtdx.so NEEDs libamdhip64.so.7 by SONAME.  PyTorch-ROCm
+        # ships its own copy with that SONAME; device pointers and streams handed across the
+        # C-ABI belong to torch's runtime, so it must be the one libtdx binds to.  Importing
+        # torch first guarantees that (loading libtdx first would pull in /opt/rocm's copy and
+        # leave the process with two runtimes -> "no ROCm-capable device").
+        import torch  # noqa: F401
+        tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(tl):
+            C.CDLL(tl, mode=C.RTLD_GLOBAL)
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)          # AttributeError if the .so lacks a declared symbol

@@ -162,6 +162,10 @@ struct tdx_mf2 {
     const float *encT, *gn1g, *gn1b, *Wenc, *pe_scale, *inv_freq, *rot_freqs, *lnfg, *lnfb, *gn2g, *gn2b, *prelu, *Wout, *bout,
         *Wtg, *btg, *Wdec1, *decT;
     int taps;
+    // optional live profiling of the dominant kernel (to_hidden GEMM): event pairs recorded on
+    // the forward's stream, read back by tdx_mf2_profile_collect after the caller synchronised.
+    std::vector<hipEvent_t> ev0, ev1;
+    size_t ev_used;
 };
 
 namespace {
@@ -454,7 +458,7 @@ int tdx_mf2_create(const tdx_mf2_config* cfg, const void* blob, size_t blob_byte
     if (e != hipSuccess) { hipFree(dev); return tdx::fail_hip(e, __FILE__, __LINE__); }
 
     tdx_mf2* h = new tdx_mf2();
-    h->device = device; h->L = L; h->dev_weights = dev; h->n_weights = host.size(); h->taps = 0;
+    h->device = device; h->L = L; h->dev_weights = dev; h->n_weights = host.size(); h->taps = 0; h->ev_used = 0;
     h->layers.resize(L);
     for (int l = 0; l < L; ++l) {
         const Off& o = offs[l]; LayerW& w = h->layers[l];
@@ -476,6 +480,8 @@ int tdx_mf2_create(const tdx_mf2_config* cfg, const void* blob, size_t blob_byte
 int tdx_mf2_destroy(tdx_mf2* h) {
     if (!h) return TDX_OK;
     if (h->dev_weights) hipFree(h->dev_weights);
+    for (auto e : h->ev0) hipEventDestroy(e);
+    for (auto e : h->ev1) hipEventDestroy(e);
     delete h;
     return TDX_OK;
 }
@@ -483,6 +489,31 @@ int tdx_mf2_destroy(tdx_mf2* h) {
 int tdx_mf2_enable_taps(tdx_mf2* h, int on) {
     if (!h) return tdx::fail(TDX_E_INVALID, "null handle");
     h->taps = on ? 1 : 0;
+    return TDX_OK;
+}
+
+int tdx_mf2_profile_enable(tdx_mf2* h, int max_records) {
+    if (!h || max_records < 0) return tdx::fail(TDX_E_INVALID, "tdx_mf2_profile_enable: bad argument");
+    for (auto e : h->ev0) hipEventDestroy(e);
+    for (auto e : h->ev1) hipEventDestroy(e);
+    h->ev0.assign(max_records, nullptr); h->ev1.assign(max_records, nullptr); h->ev_used = 0;
+    for (int i = 0; i < max_records; ++i) {
+        if (hipEventCreate(&h->ev0[i]) != hipSuccess || hipEventCreate(&h->ev1[i]) != hipSuccess)
+            return tdx::fail(TDX_E_HIP, "tdx_mf2_profile_enable: hipEventCreate failed");
+    }
+    return TDX_OK;
+}
+
+int tdx_mf2_profile_collect(tdx_mf2* h, double* total_ms, int* launches) {
+    if (!h || !total_ms || !launches) return tdx::fail(TDX_E_INVALID, "tdx_mf2_profile_collect: null argument");
+    double tot = 0;
+    for (size_t i = 0; i < h->ev_used; ++i) {
+        float ms = 0.f;
+        hipError_t e = hipEventElapsedTime(&ms, h->ev0[i], h->ev1[i]);
+        if (e != hipSuccess) return tdx::fail_hip(e, __FILE__, __LINE__);
+        tot += ms;
+    }
+    *total_ms = tot; *launches = (int)h->ev_used; h->ev_used = 0;
     return TDX_OK;
 }
 
@@ -549,7 +580,10 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
             GemmArgs g = make_args((int)M, HQ, make_seg(x, C, w.Whq, C, C));
             g.shift_k = C / 2; g.shift_S = S;
             EpiHidden e{rs, w.ghq, w.bhq, hid, HQ};
+            const bool prof = h->ev_used < h->ev0.size();
+            if (prof) hipEventRecord(h->ev0[h->ev_used], st);
             if (launch_gemm<false, false, false, true>(g, 1, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+            if (prof) { hipEventRecord(h->ev1[h->ev_used], st); h->ev_used++; }
         }
         {
             Conv17Args a{};

@@ -55,6 +55,15 @@ class MossFormer2Separator:
         self._taps = on
         self._ws = None
 
+    def profile_enable(self, max_records: int):
+        _lib.check(self._l.tdx_mf2_profile_enable(self._h, max_records))
+
+    def profile_collect(self):
+        """(total ms, launches) of the dominant GEMM since the last collect; sync first."""
+        ms = C.c_double(); n = C.c_int()
+        _lib.check(self._l.tdx_mf2_profile_collect(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def workspace_bytes(self, B, T):
         return int(self._l.tdx_mf2_workspace_bytes(self._h, B, T))
 

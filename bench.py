@@ -49,19 +49,32 @@ def synth_mixtures(batch: int, n: int, seed: int) -> np.ndarray:
     return np.clip(out, -1.0, 1.0).astype(np.float32)
 
 
+def host_cores() -> int:
+    """CPU threads this process may actually use: min(affinity, cgroup quota), capped at 16
+    (the GPU box gives a one-GPU job a 16-CPU share of a much larger host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(sd, wave_np, budget_windows: int):
     """Time the oracle on the host cores over `budget_windows` windows of the workload."""
     from oracle import mossformer2_oracle as orc          # checker / baseline leg only
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
-    x = torch.from_numpy(wave_np[:1])
     with torch.no_grad():
         t0 = time.perf_counter()
         n_done = 0
         for i in range(budget_windows):
             orc.mossformer2_forward(torch.from_numpy(wave_np[i:i + 1]), sd)
             n_done += 1
-            if time.perf_counter() - t0 > 25.0:
+            print(f"[bench] cpu_baseline window {n_done}: {time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
+            if time.perf_counter() - t0 > 20.0:
                 break
         dt = time.perf_counter() - t0
     secs = n_done * wave_np.shape[1] / 16000.0
@@ -131,6 +144,7 @@ def main():
     value = audio_s_per_step * args.steps / dt
     flops_step = sep.flops(B, T)
     if rank == 0:
+        print(f"[bench] gpu: {dt / args.steps * 1e3:.1f} ms/step, RTF {value:.1f}", file=sys.stderr, flush=True)
         M = B * S
         gemm_flops = 2.0 * M * 512 * 2176          # to_hidden+to_qk: [M,512] x [512,2176]
         ach = gemm_flops / (gemm_ms / max(gemm_launches, 1) * 1e-3) / 1e12 if gemm_launches else None

@@ -75,8 +75,26 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // Epilogue concept:  struct E { __device__ void operator()(int z, int m, int n, float v) const; }
 // PAIRED epilogue:   struct E { __device__ void operator()(int z, int m, int c, float v0, float v1) const; }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 sel4(bool ok, f32x4 v) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    return ok ? v : zero;
+}
+
+// Per-thread staging of one operand tile: 4 x 16 B global loads from clamped (always
+// in-bounds) addresses.  The validity mask is applied when the registers are written to LDS
+// (one tile later), never at load time, so the loads stay in flight across the MFMA phase.
+template <bool KMAJOR>
+struct StageAddr {
+    const float* p[4];   // address of k-tile 0
+    unsigned ok;         // bit i: element i valid (K-contiguous: row guard; K-major: unused)
+    int kr[4];           // K-major: k row within the tile
+};
+
 template <bool A_KMAJOR, bool B_KMAJOR, bool PAIRED, bool SHIFT, class Epi>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g, Epi epi) {
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
     constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = GEMM_BK, P = GEMM_PITCH;
     constexpr int A_ELEMS = A_KMAJOR ? BK * BM : BM * P;
     constexpr int B_ELEMS = B_KMAJOR ? BK * BN : BN * P;
@@ -96,148 +114,163 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g, Epi 
     const int m0 = bm * BM;
     const int n0 = PAIRED ? bn * (BN / 2) : bn * BN;
 
-    f32x16 acc[2][2];
+    f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
 
-    // staging registers: 4 float4 per operand per thread
-    float4 ra[4], rb[4];
+    // LDS addresses of this thread's staging stores (loop invariant)
+    const int i0 = tid, i1 = tid + 256, i2 = tid + 512, i3 = tid + 768;
+#define TDX_ST_A(i) (A_KMAJOR ? ((i) >> 5) * BM + ((i) & 31) * 4 : ((i) >> 3) * P + ((i) & 7) * 4)
+#define TDX_ST_B(i) (B_KMAJOR ? ((i) >> 5) * BN + ((i) & 31) * 4 : ((i) >> 3) * P + ((i) & 7) * 4)
+    const int sa0 = TDX_ST_A(i0), sa1 = TDX_ST_A(i1), sa2 = TDX_ST_A(i2), sa3 = TDX_ST_A(i3);
+    const int sb0 = TDX_ST_B(i0), sb1 = TDX_ST_B(i1), sb2 = TDX_ST_B(i2), sb3 = TDX_ST_B(i3);
+    const int ml0 = wm * 64 + l31, ml1 = ml0 + 32;
+    const int nl0 = wn * 32 + l31, nl1 = nl0 + 64;
 
     for (int s = 0; s < g.nseg; ++s) {
-        const GemmSeg sg = g.seg[s];
-        const int z1 = z / sg.zdiv, z2 = z - z1 * sg.zdiv;
-        const float* __restrict__ Ag = sg.A + (long)z1 * sg.strideA + (long)z2 * sg.strideA2;
-        const float* __restrict__ Bg = sg.B + (long)z1 * sg.strideB + (long)z2 * sg.strideB2;
-        const int nkt = sg.K / BK;
-        const int kvalid = min(sg.K, max(0, sg.ktotal - z2 * sg.kchunk));
+        const bool s0 = s == 0;
+        const int zdiv = s0 ? g.seg[0].zdiv : g.seg[1].zdiv;
+        const int z1 = z / zdiv, z2 = z - z1 * zdiv;
+        const float* __restrict__ Ag = (s0 ? g.seg[0].A : g.seg[1].A) + (long)z1 * (s0 ? g.seg[0].strideA : g.seg[1].strideA) +
+                                       (long)z2 * (s0 ? g.seg[0].strideA2 : g.seg[1].strideA2);
+        const float* __restrict__ Bg = (s0 ? g.seg[0].B : g.seg[1].B) + (long)z1 * (s0 ? g.seg[0].strideB : g.seg[1].strideB) +
+                                       (long)z2 * (s0 ? g.seg[0].strideB2 : g.seg[1].strideB2);
+        const long lda = s0 ? g.seg[0].lda : g.seg[1].lda, ldb = s0 ? g.seg[0].ldb : g.seg[1].ldb;
+        const int K = s0 ? g.seg[0].K : g.seg[1].K;
+        const int nkt = K / BK;
+        const int kvalid = min(K, max(0, (s0 ? g.seg[0].ktotal : g.seg[1].ktotal) - z2 * (s0 ? g.seg[0].kchunk : g.seg[1].kchunk)));
 
-        auto load_tile = [&](int kt) {
-            const int k0 = kt * BK;
-            // ---- A ----
-            if constexpr (!A_KMAJOR) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int idx = tid + i * GEMM_THREADS;   // 0..1023
-                    const int row = idx >> 3, c4 = idx & 7;
-                    int m = m0 + row;
-                    bool ok = m < g.M;
-                    if constexpr (SHIFT) {
-                        if (k0 < g.shift_k) {
-                            ok = ok && (m % g.shift_S != 0);
-                            m -= 1;
-                        }
-                    }
-                    ra[i] = ok ? *reinterpret_cast<const float4*>(Ag + (long)m * sg.lda + k0 + c4 * 4)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int idx = tid + i * GEMM_THREADS;
-                    const int kr = idx >> 5, c4 = idx & 31;   // 32 k-rows x 32 float4
-                    const int k = k0 + kr;
-                    const bool ok = k < kvalid;
-                    ra[i] = ok ? *reinterpret_cast<const float4*>(Ag + (long)k * sg.lda + m0 + c4 * 4)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-            // ---- B ----
-            if constexpr (!B_KMAJOR) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int idx = tid + i * GEMM_THREADS;
-                    const int row = idx >> 3, c4 = idx & 7;
-                    int n;
-                    if constexpr (PAIRED) n = (row < BN / 2) ? n0 + row : g.pair_off + n0 + row - BN / 2;
-                    else n = n0 + row;
-                    rb[i] = *reinterpret_cast<const float4*>(Bg + (long)n * sg.ldb + k0 + c4 * 4);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int idx = tid + i * GEMM_THREADS;
-                    const int kr = idx >> 5, c4 = idx & 31;
-                    const int k = k0 + kr;
-                    const int nl = c4 * 4;
-                    int n;
-                    if constexpr (PAIRED) n = (nl < BN / 2) ? n0 + nl : g.pair_off + n0 + nl - BN / 2;
-                    else n = n0 + nl;
-                    const bool ok = k < kvalid;
-                    rb[i] = ok ? *reinterpret_cast<const float4*>(Bg + (long)k * sg.ldb + n)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-        };
-        auto store_tile = [&]() {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = tid + i * GEMM_THREADS;
-                if constexpr (!A_KMAJOR) *reinterpret_cast<float4*>(As + (idx >> 3) * P + (idx & 7) * 4) = ra[i];
-                else *reinterpret_cast<float4*>(As + (idx >> 5) * BM + (idx & 31) * 4) = ra[i];
-                if constexpr (!B_KMAJOR) *reinterpret_cast<float4*>(Bs + (idx >> 3) * P + (idx & 7) * 4) = rb[i];
-                else *reinterpret_cast<float4*>(Bs + (idx >> 5) * BN + (idx & 31) * 4) = rb[i];
-            }
-        };
+        // ---- per-thread source addresses for k-tile 0 and validity ----
+        const float *pa0, *pa1, *pa2, *pa3, *pb0, *pb1, *pb2, *pb3;
+        const float *pas0 = nullptr, *pas1 = nullptr, *pas2 = nullptr, *pas3 = nullptr;   // SHIFT: shifted-row addresses
+        bool oka0 = true, oka1 = true, oka2 = true, oka3 = true;          // row guards (K-contiguous A)
+        bool oks0 = true, oks1 = true, oks2 = true, oks3 = true;          // SHIFT: validity of the shifted row
+#define TDX_A_ADDR(i, pa, pas, oka, oks)                                                   \
+        if constexpr (!A_KMAJOR) {                                                         \
+            const int m = m0 + ((i) >> 3);                                                 \
+            oka = m < g.M;                                                                 \
+            const int mc = min(m, g.M - 1);                                                \
+            pa = Ag + (long)mc * lda + ((i) & 7) * 4;                                      \
+            if constexpr (SHIFT) {                                                         \
+                oks = oka && (m % g.shift_S != 0);                                         \
+                pas = Ag + (long)max(mc - 1, 0) * lda + ((i) & 7) * 4;                     \
+            }                                                                              \
+        } else {                                                                           \
+            pa = Ag + m0 + ((i) & 31) * 4;                                                 \
+        }
+        TDX_A_ADDR(i0, pa0, pas0, oka0, oks0) TDX_A_ADDR(i1, pa1, pas1, oka1, oks1)
+        TDX_A_ADDR(i2, pa2, pas2, oka2, oks2) TDX_A_ADDR(i3, pa3, pas3, oka3, oks3)
+#define TDX_B_ADDR(i, pb)                                                                  \
+        if constexpr (!B_KMAJOR) {                                                         \
+            const int row = (i) >> 3;                                                      \
+            const int n = PAIRED ? ((row < BN / 2) ? n0 + row : g.pair_off + n0 + row - BN / 2) : n0 + row; \
+            pb = Bg + (long)n * ldb + ((i) & 7) * 4;                                       \
+        } else {                                                                           \
+            const int nl = ((i) & 31) * 4;                                                 \
+            const int n = PAIRED ? ((nl < BN / 2) ? n0 + nl : g.pair_off + n0 + nl - BN / 2) : n0 + nl; \
+            pb = Bg + n;                                                                   \
+        }
+        TDX_B_ADDR(i0, pb0) TDX_B_ADDR(i1, pb1) TDX_B_ADDR(i2, pb2) TDX_B_ADDR(i3, pb3)
+        const int kr0 = i0 >> 5, kr1 = i1 >> 5, kr2 = i2 >> 5, kr3 = i3 >> 5;   // K-major: k row in tile
 
-        load_tile(0);
+        f32x4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+        bool va0 = true, va1 = true, va2 = true, va3 = true, vb0 = true, vb1 = true, vb2 = true, vb3 = true;
+#define TDX_LOAD_A(kt, ra, va, pa, pas, oka, oks, kr)                                      \
+        if constexpr (!A_KMAJOR) {                                                         \
+            const int k0_ = (kt) * BK;                                                     \
+            if constexpr (SHIFT) {                                                         \
+                const bool sh = k0_ < g.shift_k;                                           \
+                ra = ldg4((sh ? pas : pa) + k0_); va = sh ? oks : oka;                     \
+            } else { ra = ldg4(pa + k0_); va = oka; }                                      \
+        } else {                                                                           \
+            const int k_ = (kt) * BK + kr;                                                 \
+            va = k_ < kvalid;                                                              \
+            ra = ldg4(pa + (long)min(k_, kvalid - 1) * lda);                               \
+        }
+#define TDX_LOAD_B(kt, rb, vb, pb, kr)                                                     \
+        if constexpr (!B_KMAJOR) { rb = ldg4(pb + (kt) * BK); }                            \
+        else {                                                                             \
+            const int k_ = (kt) * BK + kr;                                                 \
+            vb = k_ < kvalid;                                                              \
+            rb = ldg4(pb + (long)min(k_, kvalid - 1) * ldb);                               \
+        }
+#define TDX_LOAD_TILE(kt)                                                                  \
+        TDX_LOAD_A(kt, ra0, va0, pa0, pas0, oka0, oks0, kr0) TDX_LOAD_A(kt, ra1, va1, pa1, pas1, oka1, oks1, kr1) \
+        TDX_LOAD_A(kt, ra2, va2, pa2, pas2, oka2, oks2, kr2) TDX_LOAD_A(kt, ra3, va3, pa3, pas3, oka3, oks3, kr3) \
+        TDX_LOAD_B(kt, rb0, vb0, pb0, kr0) TDX_LOAD_B(kt, rb1, vb1, pb1, kr1)             \
+        TDX_LOAD_B(kt, rb2, vb2, pb2, kr2) TDX_LOAD_B(kt, rb3, vb3, pb3, kr3)
+
+        TDX_LOAD_TILE(0)
         for (int kt = 0; kt < nkt; ++kt) {
             __syncthreads();          // previous tile fully consumed
-            store_tile();
+            *reinterpret_cast<f32x4*>(As + sa0) = sel4(va0, ra0);
+            *reinterpret_cast<f32x4*>(As + sa1) = sel4(va1, ra1);
+            *reinterpret_cast<f32x4*>(As + sa2) = sel4(va2, ra2);
+            *reinterpret_cast<f32x4*>(As + sa3) = sel4(va3, ra3);
+            *reinterpret_cast<f32x4*>(Bs + sb0) = sel4(vb0, rb0);
+            *reinterpret_cast<f32x4*>(Bs + sb1) = sel4(vb1, rb1);
+            *reinterpret_cast<f32x4*>(Bs + sb2) = sel4(vb2, rb2);
+            *reinterpret_cast<f32x4*>(Bs + sb3) = sel4(vb3, rb3);
             __syncthreads();
-            if (kt + 1 < nkt) load_tile(kt + 1);   // in flight during the MFMA phase
+            if (kt + 1 < nkt) {       // next tile's loads stay in flight during the MFMA phase
+                TDX_LOAD_TILE(kt + 1)
+            }
 #pragma unroll
             for (int kc = 0; kc < BK / 8; ++kc) {
-                float a[2][4], b[2][4];
+                f32x4 a0, a1, b0, b1;
+                if constexpr (!A_KMAJOR) {
+                    a0 = *reinterpret_cast<const f32x4*>(As + ml0 * P + kc * 8 + h * 4);
+                    a1 = *reinterpret_cast<const f32x4*>(As + ml1 * P + kc * 8 + h * 4);
+                } else {
 #pragma unroll
-                for (int tm = 0; tm < 2; ++tm) {
-                    const int ml = wm * 64 + tm * 32 + l31;
-                    if constexpr (!A_KMAJOR) {
-                        const float4 v = *reinterpret_cast<const float4*>(As + ml * P + kc * 8 + h * 4);
-                        a[tm][0] = v.x; a[tm][1] = v.y; a[tm][2] = v.z; a[tm][3] = v.w;
-                    } else {
+                    for (int j = 0; j < 4; ++j) {
+                        a0[j] = As[(kc * 8 + h * 4 + j) * BM + ml0];
+                        a1[j] = As[(kc * 8 + h * 4 + j) * BM + ml1];
+                    }
+                }
+                if constexpr (!B_KMAJOR) {
+                    b0 = *reinterpret_cast<const f32x4*>(Bs + nl0 * P + kc * 8 + h * 4);
+                    b1 = *reinterpret_cast<const f32x4*>(Bs + nl1 * P + kc * 8 + h * 4);
+                } else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) a[tm][j] = As[(kc * 8 + h * 4 + j) * BM + ml];
+                    for (int j = 0; j < 4; ++j) {
+                        b0[j] = Bs[(kc * 8 + h * 4 + j) * BN + nl0];
+                        b1[j] = Bs[(kc * 8 + h * 4 + j) * BN + nl1];
                     }
                 }
 #pragma unroll
-                for (int tn = 0; tn < 2; ++tn) {
-                    const int nl = tn * 64 + wn * 32 + l31;
-                    if constexpr (!B_KMAJOR) {
-                        const float4 v = *reinterpret_cast<const float4*>(Bs + nl * P + kc * 8 + h * 4);
-                        b[tn][0] = v.x; b[tn][1] = v.y; b[tn][2] = v.z; b[tn][3] = v.w;
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) b[tn][j] = Bs[(kc * 8 + h * 4 + j) * BN + nl];
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc01, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc11, 0, 0, 0);
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                        for (int tn = 0; tn < 2; ++tn)
-                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
             }
         }
         __syncthreads();   // before the next segment overwrites LDS
     }
+#undef TDX_ST_A
+#undef TDX_ST_B
+#undef TDX_A_ADDR
+#undef TDX_B_ADDR
+#undef TDX_LOAD_A
+#undef TDX_LOAD_B
+#undef TDX_LOAD_TILE
 
-    // ---- epilogue ----
+    // ---- epilogue: D col = l31, row = (r&3) + 8*(r>>2) + 4*h ----
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float v0 = tm == 0 ? acc00[r] : acc10[r];
+            const float v1 = tm == 0 ? acc01[r] : acc11[r];
             if (m < g.M) {
                 if constexpr (PAIRED) {
-                    epi(z, m, n0 + wn * 32 + l31, acc[tm][0][r], acc[tm][1][r]);
+                    epi(z, m, n0 + nl0, v0, v1);
                 } else {
-                    epi(z, m, n0 + wn * 32 + l31, acc[tm][0][r]);
-                    epi(z, m, n0 + 64 + wn * 32 + l31, acc[tm][1][r]);
+                    epi(z, m, n0 + nl0, v0);
+                    epi(z, m, n0 + nl1, v1);
                 }
             }
         }

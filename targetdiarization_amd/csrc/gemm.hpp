@@ -58,6 +58,12 @@ struct GemmArgs {
     int M;            // valid rows per batch (rows >= M: A reads zero, C not stored)
     int N;            // columns (multiple of 128; PAIRED: number of pair columns, multiple of 64)
     int tiles_m, tiles_n;
+    // block -> tile mapping (both are XCD-aware: blocks with equal blockIdx.x % 8 share an XCD/L2)
+    //  map_mode 0: XCD x owns M-panels [x*mp,(x+1)*mp); it sweeps them once per group of `gw`
+    //              N-tiles, so the group's weight slice stays L2-resident while A panels stream.
+    //  map_mode 1: batched small GEMMs, 1-D grid: XCD x owns batches z = 8*j + x, so all tiles
+    //              of a batch (which share its operands) hit one L2.
+    int map_mode, mp, gw, batches;
     int pair_off;     // PAIRED: column offset of the second member of a pair
     int shift_k;      // SHIFT: k < shift_k is read from row m-1 (zero when m % shift_S == 0)
     int shift_S;
@@ -72,8 +78,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
-// Epilogue concept:  struct E { __device__ void operator()(int z, int m, int n, float v) const; }
-// PAIRED epilogue:   struct E { __device__ void operator()(int z, int m, int c, float v0, float v1) const; }
+// Epilogue concept:
+//   struct E { Col col(int z,int n) const; Row row(int z,int m) const;
+//              void store(int z,int m,int n,float v,Row,Col) const;            // plain
+//              void store2(int z,int m,int c,float v0,float v1,Row,Col) const; // PAIRED }
+struct EpiNone {};
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -93,7 +102,9 @@ struct StageAddr {
     int kr[4];           // K-major: k row within the tile
 };
 
-template <bool A_KMAJOR, bool B_KMAJOR, bool PAIRED, bool SHIFT, class Epi>
+// VARIANT != 0 are timing-only diagnostic builds reachable through tdx_linear_variant
+// (1: no global loads inside the k-loop, 2: no barriers) — results are wrong by design.
+template <bool A_KMAJOR, bool B_KMAJOR, bool PAIRED, bool SHIFT, class Epi, int VARIANT = 0>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
     constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = GEMM_BK, P = GEMM_PITCH;
     constexpr int A_ELEMS = A_KMAJOR ? BK * BM : BM * P;
@@ -106,11 +117,26 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, E
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int z = blockIdx.y;
-
-    const int nwg = g.tiles_m * g.tiles_n;
-    const int t = xcd_remap(blockIdx.x, nwg);
-    const int bm = t / g.tiles_n, bn = t % g.tiles_n;
+    int z, bm, bn;
+    {
+        const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+        if (g.map_mode == 0) {
+            z = blockIdx.y;
+            const int per = g.mp * g.gw, ngf = g.tiles_n / g.gw;
+            const int p = i / per;
+            int lm, n;
+            if (p < ngf) { const int j = i - p * per; lm = j / g.gw; n = p * g.gw + (j - lm * g.gw); }
+            else { const int rem = g.tiles_n - ngf * g.gw; const int j = i - ngf * per; lm = j / rem; n = ngf * g.gw + (j - lm * rem); }
+            bm = x * g.mp + lm; bn = n;
+            if (bm >= g.tiles_m) return;
+        } else {
+            const int tpb = g.tiles_m * g.tiles_n;
+            const int zb = i / tpb, tt = i - zb * tpb;
+            z = zb * 8 + x;
+            if (z >= g.batches) return;
+            bm = tt / g.tiles_n; bn = tt - bm * g.tiles_n;
+        }
+    }
     const int m0 = bm * BM;
     const int n0 = PAIRED ? bn * (BN / 2) : bn * BN;
 
@@ -202,7 +228,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, E
 
         TDX_LOAD_TILE(0)
         for (int kt = 0; kt < nkt; ++kt) {
-            __syncthreads();          // previous tile fully consumed
+            if (VARIANT != 2) __syncthreads();          // previous tile fully consumed
             *reinterpret_cast<f32x4*>(As + sa0) = sel4(va0, ra0);
             *reinterpret_cast<f32x4*>(As + sa1) = sel4(va1, ra1);
             *reinterpret_cast<f32x4*>(As + sa2) = sel4(va2, ra2);
@@ -211,8 +237,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, E
             *reinterpret_cast<f32x4*>(Bs + sb1) = sel4(vb1, rb1);
             *reinterpret_cast<f32x4*>(Bs + sb2) = sel4(vb2, rb2);
             *reinterpret_cast<f32x4*>(Bs + sb3) = sel4(vb3, rb3);
-            __syncthreads();
-            if (kt + 1 < nkt) {       // next tile's loads stay in flight during the MFMA phase
+            if (VARIANT != 2) __syncthreads();
+            if (VARIANT != 1 && kt + 1 < nkt) {       // next tile's loads stay in flight during the MFMA phase
                 TDX_LOAD_TILE(kt + 1)
             }
 #pragma unroll
@@ -258,6 +284,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, E
 #undef TDX_LOAD_TILE
 
     // ---- epilogue: D col = l31, row = (r&3) + 8*(r>>2) + 4*h ----
+    // per-column constants (bias, gain ...) are fetched once per lane, per-row ones once per row
+    const auto c0 = epi.col(z, n0 + nl0);
+    const auto c1 = epi.col(z, PAIRED ? n0 + nl0 : n0 + nl1);
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
@@ -266,23 +295,41 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, E
             const float v0 = tm == 0 ? acc00[r] : acc10[r];
             const float v1 = tm == 0 ? acc01[r] : acc11[r];
             if (m < g.M) {
+                const auto rw = epi.row(z, m);
                 if constexpr (PAIRED) {
-                    epi(z, m, n0 + nl0, v0, v1);
+                    epi.store2(z, m, n0 + nl0, v0, v1, rw, c0);
                 } else {
-                    epi(z, m, n0 + nl0, v0);
-                    epi(z, m, n0 + nl1, v1);
+                    epi.store(z, m, n0 + nl0, v0, rw, c0);
+                    epi.store(z, m, n0 + nl1, v1, rw, c1);
                 }
             }
         }
     }
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR, bool PAIRED, bool SHIFT, class Epi>
+template <bool A_KMAJOR, bool B_KMAJOR, bool PAIRED, bool SHIFT, class Epi, int VARIANT = 0>
 inline hipError_t launch_gemm(GemmArgs g, int batches, Epi epi, hipStream_t st) {
     g.tiles_m = (g.M + GEMM_BM - 1) / GEMM_BM;
     g.tiles_n = PAIRED ? g.N / (GEMM_BN / 2) : g.N / GEMM_BN;
-    dim3 grid(g.tiles_m * g.tiles_n, batches, 1);
-    hipLaunchKernelGGL((gemm_f32_kernel<A_KMAJOR, B_KMAJOR, PAIRED, SHIFT, Epi>), grid, dim3(GEMM_THREADS), 0, st, g, epi);
+    g.batches = batches;
+    dim3 grid;
+    if (g.tiles_m >= 16 && batches <= 4) {
+        g.map_mode = 0;
+        g.mp = (g.tiles_m + 7) / 8;
+        // N-tiles per sweep: keep the weight slice (gw x 128 rows x Ktot floats) under ~1.5 MB of the 4 MB L2
+        long ktot = 0;
+        for (int i = 0; i < g.nseg; ++i) ktot += g.seg[i].K;
+        long gw = (1536L * 1024) / (128L * ktot * 4);
+        if (gw < 1) gw = 1;
+        if (gw > g.tiles_n) gw = g.tiles_n;
+        g.gw = (int)gw;
+        grid = dim3(8 * g.mp * g.tiles_n, batches, 1);
+    } else {
+        g.map_mode = 1;
+        g.mp = 0; g.gw = 1;
+        grid = dim3(8 * ((batches + 7) / 8) * g.tiles_m * g.tiles_n, 1, 1);
+    }
+    hipLaunchKernelGGL((gemm_f32_kernel<A_KMAJOR, B_KMAJOR, PAIRED, SHIFT, Epi, VARIANT>), grid, dim3(GEMM_THREADS), 0, st, g, epi);
     return hipGetLastError();
 }
 

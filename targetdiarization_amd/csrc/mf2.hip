@@ -26,72 +26,94 @@ namespace {
 constexpr int C = 512, HID = 2048, QK = 128, HQ = HID + QK, INNER = 256;
 
 // ------------------------------------------------------------------ GEMM epilogues
+// (concept in gemm.hpp: col()/row() fetch per-column / per-row constants once, store() writes)
+struct Col2 { float a, b; };
 struct EpiHidden {   // silu(acc*rs[m]*g[n] + b[n])                      mossformer_block.py:89-102
     const float* rs; const float* g; const float* b; float* out; long ld;
-    __device__ void operator()(int, int m, int n, float v) const {
-        out[(long)m * ld + n] = siluf_acc(v * rs[m] * g[n] + b[n]);
-    }
+    __device__ Col2 col(int, int n) const { return Col2{g[n], b[n]}; }
+    __device__ float row(int, int m) const { return rs[m]; }
+    __device__ void store(int, int m, int n, float v, float r, Col2 c) const { out[(long)m * ld + n] = siluf_acc(v * r * c.a + c.b); }
 };
 struct EpiQuadSim {  // relu(acc/256)^2 with key mask                       mossformer_block.py:256-262
     float* A; int G; int S; float inv_g;
-    __device__ void operator()(int z, int m, int n, float v) const {
-        const int gi = z % G;
+    __device__ bool col(int z, int n) const { return (z % G) * 256 + n < S; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ void store(int z, int m, int n, float v, EpiNone, bool keep) const {
         float s = fmaxf(v * inv_g, 0.f);
-        s = (gi * 256 + n < S) ? s * s : 0.f;
-        A[((long)z * 256 + m) * 256 + n] = s;
+        A[((long)z * 256 + m) * 256 + n] = keep ? s * s : 0.f;
     }
 };
 struct EpiStore {    // plain store, per-batch stride
     float* out; long ld; long strideZ;
-    __device__ void operator()(int z, int m, int n, float v) const { out[(long)z * strideZ + (long)m * ld + n] = v; }
+    __device__ EpiNone col(int, int) const { return EpiNone{}; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ void store(int z, int m, int n, float v, EpiNone, EpiNone) const { out[(long)z * strideZ + (long)m * ld + n] = v; }
 };
 struct EpiAttnGate { // o = (att_u*v)*sigmoid(att_v*u)                       mossformer_block.py:217
     const float* vu; float* o; float* att_v; float* att_u; int G; int S; int E;
-    __device__ void operator()(int z, int m, int c, float av, float au) const {
-        const int b = z / G, gi = z % G;
-        const int s = gi * 256 + m;
-        if (s >= S) return;
-        const long row = (long)b * S + s;
+    __device__ EpiNone col(int, int) const { return EpiNone{}; }
+    __device__ long row(int z, int m) const {     // global token row, or -1 for group padding
+        const int b = z / G, s = (z % G) * 256 + m;
+        return s < S ? (long)b * S + s : -1L;
+    }
+    __device__ void store2(int, int, int c, float av, float au, long rw, EpiNone) const {
+        if (rw < 0) return;
         if (att_v) {  // stand-alone cal_attention: return the two attention outputs
-            att_v[row * E + c] = av;
-            att_u[row * E + c] = au;
+            att_v[rw * E + c] = av;
+            att_u[rw * E + c] = au;
         } else {
-            const float v = vu[row * (2 * E) + c], u = vu[row * (2 * E) + E + c];
-            o[row * E + c] = (au * v) * sigmoidf_acc(av * u);
+            const float v = vu[rw * (2 * E) + c], u = vu[rw * (2 * E) + E + c];
+            o[rw * E + c] = (au * v) * sigmoidf_acc(av * u);
         }
     }
 };
 struct EpiBiasPrelu { // prelu_scalar(acc + b[n])                            mossformer_block.py:405-408
     const float* b; const float* a; float* out; long ld;
-    __device__ void operator()(int, int m, int n, float v) const {
-        v += b[n];
-        out[(long)m * ld + n] = v >= 0.f ? v : a[0] * v;
+    __device__ Col2 col(int, int n) const { return Col2{b[n], a[0]}; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ void store(int, int m, int n, float v, EpiNone, Col2 c) const {
+        v += c.a;
+        out[(long)m * ld + n] = v >= 0.f ? v : c.b * v;
     }
 };
 struct EpiBiasSilu { const float* b; float* out; long ld;
-    __device__ void operator()(int, int m, int n, float v) const { out[(long)m * ld + n] = siluf_acc(v + b[n]); } };
+    __device__ float col(int, int n) const { return b[n]; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { out[(long)m * ld + n] = siluf_acc(v + c); } };
 struct EpiBiasRelu { const float* b; float* out; long ld;
-    __device__ void operator()(int, int m, int n, float v) const { out[(long)m * ld + n] = fmaxf(v + b[n], 0.f); } };
+    __device__ float col(int, int n) const { return b[n]; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { out[(long)m * ld + n] = fmaxf(v + c, 0.f); } };
 struct EpiBias { const float* b; float* out; long ld;   // b may be null
-    __device__ void operator()(int, int m, int n, float v) const { out[(long)m * ld + n] = b ? v + b[n] : v; } };
+    __device__ float col(int, int n) const { return b ? b[n] : 0.f; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { out[(long)m * ld + n] = v + c; } };
 struct EpiBiasResidual { const float* b; float* x; long ld;   // x += acc + b   mossformer_block.py:424-425
-    __device__ void operator()(int, int m, int n, float v) const { x[(long)m * ld + n] += v + b[n]; } };
+    __device__ float col(int, int n) const { return b[n]; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { x[(long)m * ld + n] += v + c; } };
 struct EpiPosEnc {   // z = acc + pe[s][n]*scale ; x = z                     mossformer2.py:490-496
     const float* pe; const float* scale; float* zout; float* x; int S;
-    __device__ void operator()(int, int m, int n, float v) const {
-        const float r = v + pe[(long)(m % S) * C + n] * scale[0];
+    __device__ float col(int, int) const { return scale[0]; }
+    __device__ int row(int, int m) const { return m % S; }
+    __device__ void store(int, int m, int n, float v, int s, float sc) const {
+        const float r = v + pe[(long)s * C + n] * sc;
         zout[(long)m * C + n] = r; x[(long)m * C + n] = r;
     }
 };
 struct EpiTanhSig {  // tanh(a+bt)*sigmoid(g+bg)                             mossformer2.py:510
     const float* bias; float* out; long strideZ;
-    __device__ void operator()(int z, int m, int c, float a, float g) const {
-        out[(long)z * strideZ + (long)m * C + c] = tanhf(a + bias[c]) * sigmoidf_acc(g + bias[C + c]);
+    __device__ Col2 col(int, int c) const { return Col2{bias[c], bias[C + c]}; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ void store2(int z, int m, int c, float a, float g, EpiNone, Col2 k) const {
+        out[(long)z * strideZ + (long)m * C + c] = tanhf(a + k.a) * sigmoidf_acc(g + k.b);
     }
 };
 struct EpiMaskMul {  // mask = relu(acc); EM = E*mask                        mossformer2.py:513-518, :576
     const float* E; float* EM; float* mask; long strideZ;
-    __device__ void operator()(int z, int m, int n, float v) const {
+    __device__ EpiNone col(int, int) const { return EpiNone{}; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ void store(int z, int m, int n, float v, EpiNone, EpiNone) const {
         v = fmaxf(v, 0.f);
         if (mask) mask[(long)z * strideZ + (long)m * C + n] = v;
         EM[(long)z * strideZ + (long)m * C + n] = v * E[(long)m * C + n];
@@ -770,6 +792,17 @@ int tdx_linear(const float* a, const float* w, const float* bias, int M, int N, 
     if (!a || !w || !c) return tdx::fail(TDX_E_INVALID, "tdx_linear: null argument");
     if (M < 1 || N % 128 || K % 32 || N < 128 || K < 32) return tdx::fail(TDX_E_INVALID, "tdx_linear: need N%128==0, K%32==0");
     return linear_gemm(a, K, w, M, N, K, EpiBias{bias, c, N}, (hipStream_t)stream);
+}
+
+// timing-only diagnostic (not declared in tdx.h): see gemm.hpp VARIANT
+int tdx_linear_variant(const float* a, const float* w, int M, int N, int K, float* c, int variant, void* stream) {
+    GemmArgs g = make_args(M, N, make_seg(a, K, w, K, K));
+    EpiStore e{c, (long)N, 0};
+    hipError_t r;
+    if (variant == 1) r = launch_gemm<false, false, false, false, EpiStore, 1>(g, 1, e, (hipStream_t)stream);
+    else if (variant == 2) r = launch_gemm<false, false, false, false, EpiStore, 2>(g, 1, e, (hipStream_t)stream);
+    else r = launch_gemm<false, false, false, false, EpiStore, 0>(g, 1, e, (hipStream_t)stream);
+    return r == hipSuccess ? TDX_OK : tdx::fail_hip(r, __FILE__, __LINE__);
 }
 
 int tdx_cosine_scores(const float* emb, const float* ref, int N, int D, float* scores, void* stream) {

@@ -109,6 +109,42 @@ int tdx_linear(const float* a_dev, const float* w_dev, const float* bias_dev, in
                float* c_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * a2  Kaldi fbank front-end ("mel frontend") — replaces torchaudio.compliance.kaldi.fbank as
+ *     called inside modelscope's ERes2NetV2 pipeline (reached from TargetASR.py:161) and
+ *     funasr's WavFrontend (reached from ASRProcessor.py:424).  [third-party algorithm]
+ *     mode 0 = speaker front-end: povey window, input in [-1,1], per-utterance mean removed
+ *     mode 1 = ASR front-end: hamming window, input x32768 (LFR/CMVN: tdx_lfr_cmvn)
+ *     wav_dev [B,N] -> feat_dev [B,F,80], F = tdx_fbank_frames(N) = 1 + (N-400)/160.
+ * ---------------------------------------------------------------------------------- */
+typedef struct tdx_fbank tdx_fbank;
+int tdx_fbank_create(int mode, int device, tdx_fbank** out);
+int tdx_fbank_destroy(tdx_fbank* h);
+int tdx_fbank_frames(int N);
+size_t tdx_fbank_workspace_bytes(int B, int N);
+int tdx_fbank_forward(tdx_fbank* h, const float* wav_dev, int B, int N, float* feat_dev,
+                      void* workspace_dev, size_t workspace_bytes, void* stream);
+/* funasr WavFrontend.apply_lfr(m=7,n=6) + apply_cmvn: feat [B,F,80] -> out [B,ceil(F/6),560],
+ * out = (stacked + shift[560]) * scale[560] */
+int tdx_lfr_cmvn(const float* feat_dev, int B, int F, const float* shift_dev, const float* scale_dev,
+                 float* out_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * a1  MDX block STFT / iSTFT — replaces ConvTDFNet.stft / .istft  AudioProcessor.py:82-120
+ *     (torch.stft(n_fft, hop, hann periodic, center=True) on chunks of hop*(dim_t-1) samples,
+ *     packed (L-re, L-im, R-re, R-im) x dim_f x dim_t; inverse zero-pads bins >= dim_f).
+ *     x_dev [R, chunk] <-> spec_dev [R, 2, dim_f, dim_t], R = n_blocks * 2 channels.
+ * ---------------------------------------------------------------------------------- */
+typedef struct tdx_stft tdx_stft;
+int tdx_stft_create(int n_fft, int hop, int dim_f, int dim_t, int device, tdx_stft** out);
+int tdx_stft_destroy(tdx_stft* h);
+int tdx_stft_chunk_size(const tdx_stft* h);
+size_t tdx_stft_workspace_bytes(const tdx_stft* h, int R);
+int tdx_stft_forward(tdx_stft* h, const float* x_dev, int R, float* spec_dev, void* workspace_dev,
+                     size_t workspace_bytes, void* stream);
+int tdx_stft_inverse(tdx_stft* h, const float* spec_dev, int R, float* y_dev, void* workspace_dev,
+                     size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * a11  cosine scoring — replaces TargetASR.cosine_similarity  TargetASR.py:144-152
  *      emb_dev [N,D] f32, ref_dev [D] f32 -> scores_dev [N] f32 (1.0 if either vector is
  *      all-zero, else cos clipped to [0,1]).

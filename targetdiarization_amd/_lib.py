@@ -39,6 +39,18 @@ SIGNATURES = {
     "tdx_dilated_dense_net": (_i, [_fp, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),
     "tdx_dilated_dense_net_workspace_bytes": (_sz, [_i, _i]),
     "tdx_linear": (_i, [_fp, _fp, _fp, _i, _i, _i, _fp, _vp]),
+    "tdx_fbank_create": (_i, [_i, _i, C.POINTER(_vp)]),
+    "tdx_fbank_destroy": (_i, [_vp]),
+    "tdx_fbank_frames": (_i, [_i]),
+    "tdx_fbank_workspace_bytes": (_sz, [_i, _i]),
+    "tdx_fbank_forward": (_i, [_vp, _fp, _i, _i, _fp, _vp, _sz, _vp]),
+    "tdx_lfr_cmvn": (_i, [_fp, _i, _i, _fp, _fp, _fp, _vp]),
+    "tdx_stft_create": (_i, [_i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "tdx_stft_destroy": (_i, [_vp]),
+    "tdx_stft_chunk_size": (_i, [_vp]),
+    "tdx_stft_workspace_bytes": (_sz, [_vp, _i]),
+    "tdx_stft_forward": (_i, [_vp, _fp, _i, _fp, _vp, _sz, _vp]),
+    "tdx_stft_inverse": (_i, [_vp, _fp, _i, _fp, _vp, _sz, _vp]),
     "tdx_cosine_scores": (_i, [_fp, _fp, _i, _i, _fp, _vp]),
 }
 

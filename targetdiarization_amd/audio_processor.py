@@ -1,0 +1,148 @@
+"""AudioProcessor — drop-in for the hot-path slice of the reference's AudioProcessor
+(/root/reference/AudioProcessor.py): same constructor signature (:125-130), same device
+convention (:205-221), same never-raise/degrade error convention (:171-202, :886-888) and
+the same `separate_speaker` contract (:885-956).  What differs is *how* it runs: all windows
+of equal length are batched into ONE device launch sequence (the reference loops with
+batch = 1), on the MI355X-native MossFormer2 (libtdx.so).
+
+Out of scope here: MDX ONNX net, enhancer, Apollo restorer, resampling,
+file I/O — those flags are accepted and degrade to "module skipped" exactly like the
+reference does when a package is disabled.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from .loudness import integrated_loudness
+from .separator import MossFormer2Separator
+
+
+class AudioProcessor:
+    def __init__(self,
+                 is_denoise_vocal: bool = False, mdx_weights_file: str = "mdx/weights/UVR-MDX-NET-Inst_HQ_3.onnx",
+                 is_enhance_vocal: bool = False, enhancer_weights_folder: str = "resemble_enhance/model_repo/enhancer_stage2",
+                 is_separate_audio: bool = False, separater_weights_folder: str = "look2hear/checkpoints/TFGNet-Noise",
+                 is_restore_audio: bool = False, restorer_weights_folder: str = "JusperLee/Apollo",
+                 verbose_log: bool = True, cuda_device: int = 0, quality: int = 2,
+                 separater_state_dict=None):
+        """`separater_state_dict` (extension): an in-memory state_dict instead of
+        `<separater_weights_folder>/best_model.pth` — no checkpoint ships with the reference."""
+        self.is_denoise_vocal = False           # MDX net body is out of scope (third-party ONNX)
+        self.is_enhance_vocal = False
+        self.is_restore_audio = False
+        self.is_separate_audio = is_separate_audio
+        self.mdx_weights_file = mdx_weights_file.replace("\\", "/")
+        self.enhancer_weights_folder = enhancer_weights_folder.replace("\\", "/")
+        self.separater_weights_folder = separater_weights_folder.replace("\\", "/").rstrip("/")
+        self.restorer_weights_folder = restorer_weights_folder.replace("\\", "/")
+        self.verbose_log = verbose_log
+        self.cuda_device = cuda_device
+        self.quality = quality
+        self.separater = None
+        self.get_device()
+        if self.is_separate_audio and (separater_state_dict is not None or os.path.isdir(self.separater_weights_folder)):
+            try:
+                self.init_separater_model(separater_state_dict)
+            except Exception as e:                       # AudioProcessor.py:189-193
+                print(f"Failed to init separater model: {e}")
+                self.is_separate_audio = False
+        else:
+            self.is_separate_audio = False
+
+    # AudioProcessor.py:205-221 — None -> auto, -1 -> cpu, n -> cuda:n
+    def get_device(self):
+        if self.cuda_device is None:
+            self.device = "cuda" if torch.cuda.is_available() else "cpu"
+        elif self.cuda_device == -1:
+            self.device = "cpu"
+        else:
+            self.device = f"cuda:{self.cuda_device}"
+            try:
+                torch.cuda.set_device(self.device)
+            except Exception as e:
+                print(f"Failed to set CUDA device: {e}")
+
+    # AudioProcessor.py:268-274 (config.yaml's model: block only carries constructor kwargs;
+    # the MI355X build supports the constructor defaults + num_blocks)
+    def init_separater_model(self, state_dict=None):
+        if str(self.device) == "cpu":
+            raise _lib.TdxError("the MI355X build has no CPU separator (cuda_device=-1 is not supported)")
+        dev = "cuda:0" if self.device == "cuda" else self.device
+        if state_dict is not None:
+            self.separater = MossFormer2Separator(state_dict, device=dev)
+        else:
+            self.separater = MossFormer2Separator.from_pretrain(f"{self.separater_weights_folder}/best_model.pth", device=dev)
+        self.separater.eval()
+
+    # AudioProcessor.py:1123-1127
+    def meter_loudness(self, audio_data: np.ndarray, sampling_rate: int):
+        return round(integrated_loudness(audio_data, sampling_rate), 1)
+
+    @staticmethod
+    def window_plan(n: int, window_size: int = 160000, start: int = 0):
+        """[start,end) windows for one VAD frame — AudioProcessor.py:920-935."""
+        starts, ends = [], []
+        k = n // window_size
+        if k == 0:
+            starts.append(start); ends.append(start + n)
+        else:
+            for j in range(k):
+                starts.append(start + j * window_size); ends.append(start + (j + 1) * window_size)
+            if n % window_size > 0:
+                if n % window_size > window_size / 2:
+                    starts.append(ends[-1]); ends.append(start + n)
+                else:
+                    ends[-1] = start + n
+        return list(zip(starts, ends))
+
+    def separate_windows(self, windows):
+        """Run the separator on a list of 1-D float32 windows; windows of equal length share one
+        batched forward (bit-compatible with B=1: the model has no cross-sample op and the
+        reference never pads a batch, mossformer_block.py:485).  Returns list of [2,T] arrays."""
+        out = [None] * len(windows)
+        by_len = {}
+        for i, w in enumerate(windows):
+            by_len.setdefault(len(w), []).append(i)
+        dev = self.separater.device
+        for T, idxs in by_len.items():
+            for c in range(0, len(idxs), 32):                # bound the workspace: <= 32 windows / launch
+                chunk = idxs[c:c + 32]
+                x = torch.from_numpy(np.stack([windows[i] for i in chunk]).astype(np.float32, copy=False)).to(dev)
+                y = self.separater(x).cpu().numpy()
+                for j, i in enumerate(chunk):
+                    out[i] = y[j]
+        return out
+
+    # AudioProcessor.py:885-956
+    def separate_speaker(self, audio_data: np.ndarray, sampling_rate: int = 16000, low_gpu_ram: bool = False):
+        if not self.is_separate_audio:
+            print("\nSkip module: separate_speaker")
+            return audio_data, audio_data
+        if sampling_rate != 16000:
+            print("separate_speaker: resampling is outside the MI355X hot path; pass 16 kHz audio")
+            return audio_data, audio_data
+        if low_gpu_ram:
+            print("separate_speaker: low_gpu_ram (1 s windows + silero VAD) is not needed on 288 GB HBM; using 10 s windows")
+        window_size = 160000
+        if self.verbose_log:
+            print("\nRunning module: separate_speaker")
+            print(f"Window size: {window_size}")
+            print("Use VAD: False")
+        if audio_data.shape[0] < 16:
+            # MossFormer2's encoder needs >= kernel_size samples (the reference would raise inside conv1d)
+            return audio_data, audio_data
+        plan = self.window_plan(audio_data.shape[0], window_size)
+        wins = [audio_data[s:e].astype(np.float32, copy=True) for s, e in plan]
+        outs = self.separate_windows(wins)
+        spk1 = np.concatenate([o[0] for o in outs]).astype(np.float32)
+        spk2 = np.concatenate([o[1] for o in outs]).astype(np.float32)
+        try:                                                  # louder stream first, :949-952
+            if self.meter_loudness(spk1, 16000) < self.meter_loudness(spk2, 16000):
+                spk1, spk2 = spk2, spk1
+        except ValueError:
+            pass                                              # clip shorter than one 400 ms gating block
+        return spk1, spk2

@@ -1,0 +1,350 @@
+// frontend.hip — spectral front-ends of the path on MI355X:
+//   * Kaldi-compatible 80-bin log-mel fbank (25 ms / 10 ms, 512-point) for the speaker
+//     embedding (povey window, per-utterance mean removal) and the ASR front-end
+//     (hamming, x32768, LFR 7/6 + CMVN)            [third-party torchaudio/funasr algorithm]
+//   * the MDX block STFT / iSTFT pair: torch.stft(n_fft=6144, hop, hann periodic, center)
+//     with the reference's (L-re, L-im, R-re, R-im) x dim_f x dim_t packing
+//                                                   AudioProcessor.py:82-120
+// Both transforms are evaluated as DFT-matrix GEMMs on the fp32 MFMA core (gemm.hpp):
+// n_fft = 6144 = 3*2^11 would need a mixed-radix FFT, the whole STFT stage is ~2 % of the
+// path's FLOPs even in matrix form, and the matrix form reuses the one tuned kernel and has
+// FFT-grade error (each output is a single fp32 FMA chain over exactly-rounded twiddles).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <vector>
+
+#include "../../include/tdx.h"
+#include "gemm.hpp"
+#include "devutil.hpp"
+#include "tdx_common.hpp"
+
+using namespace tdx;
+
+namespace {
+
+constexpr int NF = 512, NBIN_PAD = 320, NMEL = 80, FLEN = 400, FSHIFT = 160;
+constexpr float LOG_EPS = 1.1920928955078125e-07f;
+
+inline size_t al(size_t n) { return (n + 63) / 64 * 64; }
+
+#define LAUNCH_CHECK()                                    \
+    do {                                                  \
+        hipError_t e__ = hipGetLastError();               \
+        if (e__ != hipSuccess) return tdx::fail_hip(e__, __FILE__, __LINE__); \
+    } while (0)
+
+// one block (256 threads) per frame: scale, DC removal, pre-emphasis 0.97 (replicate-left),
+// window, zero-pad 400 -> 512     [kaldi.fbank _get_window]
+__global__ __launch_bounds__(256) void fbank_frame_kernel(const float* __restrict__ wav, const float* __restrict__ win,
+                                                           float* __restrict__ frames, int N, int F, float scale) {
+    __shared__ float x[FLEN];
+    __shared__ float red[4];
+    const int f = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float* src = wav + (long)b * N + (long)f * FSHIFT;
+    float s = 0.f;
+    for (int i = tid; i < FLEN; i += 256) { const float v = src[i] * scale; x[i] = v; s += v; }
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) * (1.0f / FLEN);
+    float* dst = frames + ((long)b * F + f) * NF;
+    for (int i = tid; i < NF; i += 256) {
+        float v = 0.f;
+        if (i < FLEN) {
+            const float cur = x[i] - mean, prev = x[i > 0 ? i - 1 : 0] - mean;
+            v = (cur - 0.97f * prev) * win[i];
+        }
+        dst[i] = v;
+    }
+}
+
+struct EpiPower {   // |X_k|^2 from the (cos, -sin) column pair
+    float* P;
+    __device__ EpiNone col(int, int) const { return EpiNone{}; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ void store2(int, int m, int c, float re, float im, EpiNone, EpiNone) const { P[(long)m * NBIN_PAD + c] = re * re + im * im; }
+};
+struct EpiLogMel {  // log(max(mel energy, eps)), 80 of the 128 padded columns kept
+    float* out;
+    __device__ EpiNone col(int, int) const { return EpiNone{}; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ void store(int, int m, int n, float v, EpiNone, EpiNone) const {
+        if (n < NMEL) out[(long)m * NMEL + n] = logf(fmaxf(v, LOG_EPS));
+    }
+};
+
+// SV: feat -= mean over frames (per utterance, per bin).  one block per utterance.
+__global__ __launch_bounds__(320) void fbank_submean_kernel(float* __restrict__ feat, int F) {
+    __shared__ double part[4][NMEL];
+    const int b = blockIdx.x, d = threadIdx.x % NMEL, g = threadIdx.x / NMEL;
+    float* p = feat + (long)b * F * NMEL;
+    double s = 0.0;
+    for (int f = g; f < F; f += 4) s += (double)p[(long)f * NMEL + d];
+    part[g][d] = s;
+    __syncthreads();
+    const float mean = (float)((part[0][d] + part[1][d] + part[2][d] + part[3][d]) / (double)F);
+    for (int f = g; f < F; f += 4) p[(long)f * NMEL + d] -= mean;
+}
+
+// ASR: LFR (stack 7, stride 6, 3 left copies of frame 0, repeat last frame) + CMVN
+__global__ void lfr_cmvn_kernel(const float* __restrict__ feat, const float* __restrict__ shift, const float* __restrict__ scl,
+                                float* __restrict__ out, int F, int Fl) {
+    const int i = blockIdx.x, b = blockIdx.y;
+    for (int c = threadIdx.x; c < 7 * NMEL; c += blockDim.x) {
+        const int j = c / NMEL, d = c - j * NMEL;
+        int src = i * 6 + j - 3;
+        src = src < 0 ? 0 : (src > F - 1 ? F - 1 : src);
+        out[((long)b * Fl + i) * 560 + c] = (feat[((long)b * F + src) * NMEL + d] + shift[c]) * scl[c];
+    }
+}
+
+// ---------------------------------------------------------------- STFT / iSTFT (MDX geometry)
+__global__ __launch_bounds__(256) void stft_frame_kernel(const float* __restrict__ x, const float* __restrict__ win,
+                                                          float* __restrict__ frames, int chunk, int nfft, int hop, int T) {
+    const int t = blockIdx.x, r = blockIdx.y;
+    const float* src = x + (long)r * chunk;
+    float* dst = frames + ((long)r * T + t) * nfft;
+    for (int n = threadIdx.x; n < nfft; n += 256) {
+        int p = t * hop + n - nfft / 2;                 // torch.stft(center=True): reflect padding
+        if (p < 0) p = -p;
+        if (p >= chunk) p = 2 * (chunk - 1) - p;
+        dst[n] = src[p] * win[n];
+    }
+}
+struct EpiSpec {   // C[m=(ri,f)][n=(r,t)] -> spec[r][ri][f][t]      AudioProcessor.py:93-98
+    float* spec; int dimf; int T;
+    __device__ EpiNone col(int, int) const { return EpiNone{}; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ void store(int, int m, int n, float v, EpiNone, EpiNone) const {
+        const int ri = m / dimf, f = m - ri * dimf, r = n / T, t = n - r * T;
+        spec[(((long)r * 2 + ri) * dimf + f) * T + t] = v;
+    }
+};
+struct EpiWinFrame {  // irfft frame * window
+    const float* win; float* out; int nfft; long strideZ;
+    __device__ float col(int, int n) const { return win[n]; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ void store(int z, int m, int n, float v, EpiNone, float w) const { out[(long)z * strideZ + (long)m * nfft + n] = v * w; }
+};
+// overlap-add / window envelope, centre trim   (torch.istft, center=True)
+__global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ frames, const float* __restrict__ env,
+                                                         float* __restrict__ y, int chunk, int nfft, int hop, int T) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (i >= chunk) return;
+    const int p = (int)i + nfft / 2;
+    int t1 = p / hop; if (t1 > T - 1) t1 = T - 1;
+    const int t0 = p >= nfft ? (p - nfft) / hop : 0;      // conservative lower bound; exact test below
+    float acc = 0.f;
+    for (int t = t0; t <= t1; ++t) {
+        const int n = p - t * hop;
+        if (n >= 0 && n < nfft) acc += frames[((long)r * T + t) * nfft + n];
+    }
+    y[(long)r * chunk + i] = acc / env[p];
+}
+
+}  // namespace
+
+struct tdx_fbank {
+    int mode; float scale;
+    float* dev; const float *Wdft, *mel, *win;
+};
+struct tdx_stft {
+    int nfft, hop, dimf, T, chunk;
+    float* dev; const float *Wf, *Wi, *win, *env;
+};
+
+extern "C" {
+
+int tdx_fbank_create(int mode, int device, tdx_fbank** out) {
+    if (!out || (mode != 0 && mode != 1)) return tdx::fail(TDX_E_INVALID, "tdx_fbank_create: mode must be 0 (SV) or 1 (ASR)");
+    std::vector<float> host;
+    const size_t oW = 0, nW = (size_t)2 * NBIN_PAD * NF;
+    host.resize(al(nW), 0.f);
+    std::vector<double> cs(NF), sn(NF);
+    for (int i = 0; i < NF; ++i) { cs[i] = cos(2.0 * M_PI * i / NF); sn[i] = sin(2.0 * M_PI * i / NF); }
+    for (int k = 0; k <= NF / 2; ++k)
+        for (int n = 0; n < NF; ++n) {
+            const int idx = (int)(((long)k * n) % NF);
+            host[oW + (size_t)k * NF + n] = (float)cs[idx];
+            host[oW + (size_t)(NBIN_PAD + k) * NF + n] = (float)(-sn[idx]);
+        }
+    // mel banks [128][320] (torchaudio get_mel_banks; last FFT bin column is zero)
+    const size_t oM = host.size();
+    host.resize(oM + al((size_t)128 * NBIN_PAD), 0.f);
+    {
+        auto mel = [](double f) { return 1127.0 * log(1.0 + f / 700.0); };
+        const double mlow = mel(20.0), mhigh = mel(8000.0), delta = (mhigh - mlow) / (NMEL + 1);
+        for (int b = 0; b < NMEL; ++b) {
+            const double left = mlow + b * delta, center = left + delta, right = center + delta;
+            for (int k = 0; k < NF / 2; ++k) {
+                const double m = mel(31.25 * k);
+                const double up = (m - left) / (center - left), down = (right - m) / (right - center);
+                const double v = fmax(0.0, fmin(up, down));
+                host[oM + (size_t)b * NBIN_PAD + k] = (float)v;
+            }
+        }
+    }
+    const size_t oWin = host.size();
+    host.resize(oWin + al(FLEN), 0.f);
+    for (int i = 0; i < FLEN; ++i) {
+        if (mode == 0) host[oWin + i] = (float)pow(0.5 - 0.5 * cos(2.0 * M_PI * i / (FLEN - 1)), 0.85);   // povey
+        else host[oWin + i] = (float)(0.54 - 0.46 * cos(2.0 * M_PI * i / (FLEN - 1)));                     // hamming
+    }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return tdx::fail_hip(e, __FILE__, __LINE__);
+    float* dev = nullptr;
+    e = hipMalloc(&dev, host.size() * sizeof(float));
+    if (e != hipSuccess) return tdx::fail_hip(e, __FILE__, __LINE__);
+    e = hipMemcpy(dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(dev); return tdx::fail_hip(e, __FILE__, __LINE__); }
+    tdx_fbank* h = new tdx_fbank();
+    h->mode = mode; h->scale = mode == 1 ? 32768.0f : 1.0f; h->dev = dev; h->Wdft = dev + oW; h->mel = dev + oM; h->win = dev + oWin;
+    *out = h;
+    return TDX_OK;
+}
+
+int tdx_fbank_destroy(tdx_fbank* h) {
+    if (h) { if (h->dev) hipFree(h->dev); delete h; }
+    return TDX_OK;
+}
+
+int tdx_fbank_frames(int N) { return N < FLEN ? 0 : 1 + (N - FLEN) / FSHIFT; }
+
+size_t tdx_fbank_workspace_bytes(int B, int N) {
+    const int F = tdx_fbank_frames(N);
+    if (B < 1 || F < 1) return 0;
+    return (al((size_t)B * F * NF) + al((size_t)B * F * NBIN_PAD)) * sizeof(float);
+}
+
+int tdx_fbank_forward(tdx_fbank* h, const float* wav, int B, int N, float* feat, void* ws_, size_t ws_bytes, void* stream) {
+    if (!h || !wav || !feat || !ws_) return tdx::fail(TDX_E_INVALID, "tdx_fbank_forward: null argument");
+    const int F = tdx_fbank_frames(N);
+    if (B < 1 || F < 1) return tdx::fail(TDX_E_INVALID, "tdx_fbank_forward: need N >= 400 samples");
+    if (ws_bytes < tdx_fbank_workspace_bytes(B, N)) return tdx::fail(TDX_E_WORKSPACE, "tdx_fbank_forward: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* frames = (float*)ws_;
+    float* P = frames + al((size_t)B * F * NF);
+    const int M = B * F;
+    hipLaunchKernelGGL(fbank_frame_kernel, dim3(F, B), dim3(256), 0, st, wav, h->win, frames, N, F, h->scale);
+    LAUNCH_CHECK();
+    {
+        GemmArgs g = make_args(M, NBIN_PAD, make_seg(frames, NF, h->Wdft, NF, NF));
+        g.pair_off = NBIN_PAD;
+        if (launch_gemm<false, false, true, false>(g, 1, EpiPower{P}, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    }
+    {
+        GemmArgs g = make_args(M, 128, make_seg(P, NBIN_PAD, h->mel, NBIN_PAD, NBIN_PAD));
+        if (launch_gemm<false, false, false, false>(g, 1, EpiLogMel{feat}, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    }
+    if (h->mode == 0) {
+        hipLaunchKernelGGL(fbank_submean_kernel, dim3(B), dim3(320), 0, st, feat, F);
+        LAUNCH_CHECK();
+    }
+    return TDX_OK;
+}
+
+int tdx_lfr_cmvn(const float* feat, int B, int F, const float* shift, const float* scale, float* out, void* stream) {
+    if (!feat || !shift || !scale || !out || B < 1 || F < 1) return tdx::fail(TDX_E_INVALID, "tdx_lfr_cmvn: bad argument");
+    const int Fl = (F + 5) / 6;
+    hipLaunchKernelGGL(lfr_cmvn_kernel, dim3(Fl, B), dim3(256), 0, (hipStream_t)stream, feat, shift, scale, out, F, Fl);
+    LAUNCH_CHECK();
+    return TDX_OK;
+}
+
+// ------------------------------------------------------------------------------ STFT
+int tdx_stft_create(int n_fft, int hop, int dim_f, int dim_t, int device, tdx_stft** out) {
+    if (!out || n_fft < 256 || n_fft % 128 || hop < 1 || dim_f < 128 || dim_f % 64 || dim_f > n_fft / 2 + 1 || dim_t < 128 ||
+        dim_t % 128 || (long)hop * (dim_t - 1) <= n_fft / 2)
+        return tdx::fail(TDX_E_INVALID, "tdx_stft_create: unsupported geometry (need n_fft%128==0, dim_f%64==0, dim_t%128==0)");
+    const int N = n_fft, T = dim_t, chunk = hop * (dim_t - 1);
+    std::vector<double> cs(N), sn(N);
+    for (int i = 0; i < N; ++i) { cs[i] = cos(2.0 * M_PI * i / N); sn[i] = sin(2.0 * M_PI * i / N); }
+    std::vector<float> host;
+    // forward: rows m = ri*dim_f + f over k=n (time):  re: cos, im: -sin
+    const size_t oWf = 0;
+    host.resize(al((size_t)2 * dim_f * N), 0.f);
+    for (int f = 0; f < dim_f; ++f)
+        for (int n = 0; n < N; ++n) {
+            const int idx = (int)(((long)f * n) % N);
+            host[oWf + (size_t)f * N + n] = (float)cs[idx];
+            host[oWf + (size_t)(dim_f + f) * N + n] = (float)(-sn[idx]);
+        }
+    // inverse (c2r, bins >= dim_f are zero): rows n (time) over k = ri*dim_f + f
+    //   y[n] = 1/N [X0.re + 2 sum_{f>=1} (X_f.re cos - X_f.im sin)] (+ Nyquist term if dim_f covers it)
+    const size_t oWi = host.size();
+    host.resize(oWi + al((size_t)N * 2 * dim_f), 0.f);
+    for (int n = 0; n < N; ++n)
+        for (int f = 0; f < dim_f; ++f) {
+            const int idx = (int)(((long)f * n) % N);
+            const bool edge = (f == 0) || (2 * f == N);
+            const double wgt = (edge ? 1.0 : 2.0) / N;
+            host[oWi + (size_t)n * 2 * dim_f + f] = (float)(wgt * cs[idx]);
+            host[oWi + (size_t)n * 2 * dim_f + dim_f + f] = edge ? 0.f : (float)(-wgt * sn[idx]);
+        }
+    const size_t oWin = host.size();
+    host.resize(oWin + al(N), 0.f);
+    std::vector<double> w(N);
+    for (int i = 0; i < N; ++i) { w[i] = 0.5 - 0.5 * cos(2.0 * M_PI * i / N); host[oWin + i] = (float)w[i]; }   // hann, periodic
+    const size_t oEnv = host.size();
+    const int L = N + hop * (T - 1);
+    host.resize(oEnv + al(L), 0.f);
+    for (int t = 0; t < T; ++t)
+        for (int n = 0; n < N; ++n) host[oEnv + (size_t)t * hop + n] += (float)((double)host[oWin + n] * (double)host[oWin + n]);
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return tdx::fail_hip(e, __FILE__, __LINE__);
+    float* dev = nullptr;
+    e = hipMalloc(&dev, host.size() * sizeof(float));
+    if (e != hipSuccess) return tdx::fail_hip(e, __FILE__, __LINE__);
+    e = hipMemcpy(dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(dev); return tdx::fail_hip(e, __FILE__, __LINE__); }
+    tdx_stft* h = new tdx_stft();
+    h->nfft = N; h->hop = hop; h->dimf = dim_f; h->T = T; h->chunk = chunk; h->dev = dev;
+    h->Wf = dev + oWf; h->Wi = dev + oWi; h->win = dev + oWin; h->env = dev + oEnv;
+    *out = h;
+    return TDX_OK;
+}
+
+int tdx_stft_destroy(tdx_stft* h) {
+    if (h) { if (h->dev) hipFree(h->dev); delete h; }
+    return TDX_OK;
+}
+
+int tdx_stft_chunk_size(const tdx_stft* h) { return h ? h->chunk : 0; }
+
+size_t tdx_stft_workspace_bytes(const tdx_stft* h, int R) {
+    if (!h || R < 1) return 0;
+    return al((size_t)R * h->T * h->nfft) * sizeof(float);
+}
+
+// x_dev [R, chunk] -> spec_dev [R, 2, dim_f, dim_t]  (R = n_blocks*2 channels; viewed by the
+// caller as [n_blocks, 4, dim_f, dim_t] = (L-re, L-im, R-re, R-im))
+int tdx_stft_forward(tdx_stft* h, const float* x, int R, float* spec, void* ws_, size_t ws_bytes, void* stream) {
+    if (!h || !x || !spec || !ws_ || R < 1) return tdx::fail(TDX_E_INVALID, "tdx_stft_forward: bad argument");
+    if (ws_bytes < tdx_stft_workspace_bytes(h, R)) return tdx::fail(TDX_E_WORKSPACE, "tdx_stft_forward: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* frames = (float*)ws_;
+    hipLaunchKernelGGL(stft_frame_kernel, dim3(h->T, R), dim3(256), 0, st, x, h->win, frames, h->chunk, h->nfft, h->hop, h->T);
+    LAUNCH_CHECK();
+    GemmArgs g = make_args(2 * h->dimf, R * h->T, make_seg(h->Wf, h->nfft, frames, h->nfft, h->nfft));
+    if (launch_gemm<false, false, false, false>(g, 1, EpiSpec{spec, h->dimf, h->T}, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    return TDX_OK;
+}
+
+// spec_dev [R, 2, dim_f, dim_t] -> y_dev [R, chunk]   (bins >= dim_f taken as zero: freq_pad)
+int tdx_stft_inverse(tdx_stft* h, const float* spec, int R, float* y, void* ws_, size_t ws_bytes, void* stream) {
+    if (!h || !spec || !y || !ws_ || R < 1) return tdx::fail(TDX_E_INVALID, "tdx_stft_inverse: bad argument");
+    if (ws_bytes < tdx_stft_workspace_bytes(h, R)) return tdx::fail(TDX_E_WORKSPACE, "tdx_stft_inverse: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* frames = (float*)ws_;
+    const int K = 2 * h->dimf;
+    GemmArgs g = make_args(h->T, h->nfft, make_seg(spec, h->T, h->Wi, K, K, (long)K * h->T, 0));
+    if (launch_gemm<true, false, false, false>(g, R, EpiWinFrame{h->win, frames, h->nfft, (long)h->T * h->nfft}, st) != hipSuccess)
+        return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    hipLaunchKernelGGL(istft_ola_kernel, dim3((h->chunk + 255) / 256, R), dim3(256), 0, st, frames, h->env, y, h->chunk, h->nfft, h->hop, h->T);
+    LAUNCH_CHECK();
+    return TDX_OK;
+}
+
+}  // extern "C"

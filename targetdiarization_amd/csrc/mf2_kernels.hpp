@@ -7,20 +7,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace tdx {
+#include "devutil.hpp"
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float siluf_acc(float x) { return x / (1.0f + expf(-x)); }
+namespace tdx {
 
 // ---------------------------------------------------------------------------------------
 // Encoder: E[b,s,c] = relu(sum_t w[c,t] * wav[b, 8s+t])   (mossformer2.py:157-210)

@@ -1,0 +1,72 @@
+"""-m gpu parity tests of the spectral front-ends."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+dev = torch.device("cuda:0")
+
+
+def rel_l2(a, b):
+    a = a.detach().double().cpu().reshape(-1); b = torch.as_tensor(b).double().cpu().reshape(-1)
+    return float((a - b).norm() / b.norm())
+
+
+def _speechlike(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(n) / 16000.0
+    return (0.1 * torch.randn(n, generator=g) * (0.5 - 0.5 * torch.cos(2 * np.pi * 3.0 * t)) + 0.02 * torch.sin(2 * np.pi * 220 * t)).float()
+
+
+def test_fbank_sv_and_asr_vs_oracle():
+    """Kaldi fbank restatement (oracle/frontend_oracle.py, parity unpinned: third-party algorithm).
+    Tolerance: 1e-4 relative on the log-mel features (BASELINE rel-fp)."""
+    from oracle import frontend_oracle as fo
+    from targetdiarization_amd.frontend import Fbank, lfr_cmvn
+    sv, asr = Fbank("sv", dev), Fbank("asr", dev)
+    for n in (400, 559, 560, 16000, 30768, 160000):
+        x = _speechlike(n, n)
+        ref = fo.sv_features(x.double())
+        out = sv(x.to(dev))[0]
+        assert out.shape == ref.shape
+        assert rel_l2(out, ref) < 1e-4, n
+        g = torch.Generator().manual_seed(7)
+        shift = torch.randn(560, generator=g); scale = torch.rand(560, generator=g) + 0.5
+        ref2 = fo.asr_features(x.double(), shift.double(), scale.double())
+        f = asr(x.to(dev))
+        out2 = lfr_cmvn(f, shift.to(dev), scale.to(dev))[0]
+        assert out2.shape == ref2.shape
+        assert rel_l2(out2, ref2) < 1e-4, n
+    # batch rows independent
+    xb = torch.stack([_speechlike(8000, 1), _speechlike(8000, 2)])
+    ob = sv(xb.to(dev))
+    assert rel_l2(ob[1], fo.sv_features(xb[1].double())) < 1e-4
+
+
+def test_block_stft_vs_torch_stft():
+    """ConvTDFNet.stft/.istft (AudioProcessor.py:82-120) — torch.stft/istft on CPU IS the
+    reference's implementation of this row, so parity here is pinned.  Small geometry for the
+    CPU side (n_fft 768 = 3*256 keeps the non-power-of-two factor), then the MDX geometry."""
+    from targetdiarization_amd.frontend import BlockSTFT
+    for (n_fft, hop, dim_f, dim_t, nblk) in [(768, 256, 384, 128, 2), (6144, 2048, 3072, 256, 1)]:
+        st = BlockSTFT(n_fft, hop, dim_f, dim_t, dev)
+        chunk = hop * (dim_t - 1)
+        assert st.chunk_size == chunk
+        g = torch.Generator().manual_seed(n_fft)
+        x = (torch.rand(nblk, 2, chunk, generator=g) - 0.5)
+        win = torch.hann_window(n_fft, periodic=True)
+        ref = torch.stft(x.reshape(-1, chunk), n_fft=n_fft, hop_length=hop, window=win, center=True, return_complex=True)
+        ref = torch.view_as_real(ref).permute(0, 3, 1, 2).reshape(-1, 2, 2, n_fft // 2 + 1, dim_t).reshape(-1, 4, n_fft // 2 + 1, dim_t)
+        ref = ref[:, :, :dim_f].contiguous()
+        spec = st.stft(x.to(dev))
+        assert spec.shape == ref.shape
+        assert rel_l2(spec, ref) < 1e-5
+        # inverse of the reference's own (dim_f-truncated) spectrum
+        pad = torch.zeros(ref.shape[0], 4, n_fft // 2 + 1 - dim_f, dim_t)
+        xr = torch.cat([ref, pad], -2).reshape(-1, 2, n_fft // 2 + 1, dim_t).permute(0, 2, 3, 1).contiguous()
+        yref = torch.istft(torch.view_as_complex(xr), n_fft=n_fft, hop_length=hop, window=win, center=True).reshape(-1, 2, chunk)
+        y = st.istft(ref.to(dev))
+        assert rel_l2(y, yref) < 1e-5
+        # round trip through the device pair reproduces the dim_f-band-limited signal
+        y2 = st.istft(spec)
+        assert rel_l2(y2, yref) < 1e-5

@@ -29,7 +29,10 @@ def test_fbank_sv_and_asr_vs_oracle():
         ref = fo.sv_features(x.double())
         out = sv(x.to(dev))[0]
         assert out.shape == ref.shape
-        assert rel_l2(out, ref) < 1e-4, n
+        if ref.shape[0] == 1:       # one frame: mean removal leaves exact zeros on both sides
+            assert float(out.abs().max()) < 1e-6
+        else:
+            assert rel_l2(out, ref) < 1e-4, n
         g = torch.Generator().manual_seed(7)
         shift = torch.randn(560, generator=g); scale = torch.rand(560, generator=g) + 0.5
         ref2 = fo.asr_features(x.double(), shift.double(), scale.double())

@@ -145,6 +145,23 @@ int tdx_stft_inverse(tdx_stft* h, const float* spec_dev, int R, float* y_dev, vo
                      size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * a12 Paraformer-large SANM encoder — replaces the encoder forward inside
+ *     `self.asr['paraformer'].generate(input=wav, hotword=...)`  ASRProcessor.py:424
+ *     (funasr SANMEncoder: third-party; 1+49 pre-LN layers, d=512, 4 heads, FSMN memory k=11).
+ *     blob: TDXW container with funasr's names (encoder.encoders0.0.*, encoder.encoders.{i}.*,
+ *     encoder.after_norm.*).  feats_dev [B,T,560] (tdx_lfr_cmvn output) -> out_dev [B,T,512].
+ *     lens_host: NULL, or B lengths that must all equal T (callers bucket segments by length,
+ *     as for the separator; no padding mask is implemented).
+ * ---------------------------------------------------------------------------------- */
+typedef struct tdx_pfenc tdx_pfenc;
+int tdx_pfenc_create(int num_blocks, const void* weights_blob, size_t blob_bytes, int device, tdx_pfenc** out);
+int tdx_pfenc_destroy(tdx_pfenc* h);
+size_t tdx_pfenc_workspace_bytes(const tdx_pfenc* h, int B, int T);
+double tdx_pfenc_flops(const tdx_pfenc* h, int B, int T);
+int tdx_pfenc_forward(tdx_pfenc* h, const float* feats_dev, const int* lens_host, int B, int T,
+                      float* out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * a11  cosine scoring — replaces TargetASR.cosine_similarity  TargetASR.py:144-152
  *      emb_dev [N,D] f32, ref_dev [D] f32 -> scores_dev [N] f32 (1.0 if either vector is
  *      all-zero, else cos clipped to [0,1]).

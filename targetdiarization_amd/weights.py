@@ -140,6 +140,52 @@ def recipe_state_dict(seed: int = 0, num_blocks: int = 24, **kw) -> "OrderedDict
     return out
 
 
+def paraformer_encoder_param_shapes(num_blocks: int = 50, d: int = 512, d_in: int = 560, ffn: int = 2048,
+                                    ksize: int = 11) -> "OrderedDict[str, tuple]":
+    """funasr SANMEncoder state_dict layout [upstream-recall, SURVEY Appendix B.4]: one
+    `encoders0` layer (560 -> 512) + num_blocks-1 `encoders` layers + after_norm."""
+    s = OrderedDict()
+
+    def layer(p, din):
+        s[p + "self_attn.linear_out.weight"] = (d, d)
+        s[p + "self_attn.linear_out.bias"] = (d,)
+        s[p + "self_attn.linear_q_k_v.weight"] = (3 * d, din)
+        s[p + "self_attn.linear_q_k_v.bias"] = (3 * d,)
+        s[p + "self_attn.fsmn_block.weight"] = (d, 1, ksize)
+        s[p + "feed_forward.w_1.weight"] = (ffn, d)
+        s[p + "feed_forward.w_1.bias"] = (ffn,)
+        s[p + "feed_forward.w_2.weight"] = (d, ffn)
+        s[p + "feed_forward.w_2.bias"] = (d,)
+        s[p + "norm1.weight"] = (din,)
+        s[p + "norm1.bias"] = (din,)
+        s[p + "norm2.weight"] = (d,)
+        s[p + "norm2.bias"] = (d,)
+
+    layer("encoder.encoders0.0.", d_in)
+    for i in range(num_blocks - 1):
+        layer(f"encoder.encoders.{i}.", d)
+    s["encoder.after_norm.weight"] = (d,)
+    s["encoder.after_norm.bias"] = (d,)
+    return s
+
+
+def recipe_paraformer_state_dict(seed: int = 0, num_blocks: int = 50) -> "OrderedDict[str, torch.Tensor]":
+    out = OrderedDict()
+    for name, shape in paraformer_encoder_param_shapes(num_blocks).items():
+        n = int(np.prod(shape))
+        u = torch.from_numpy(philox_uniform("pf:" + name, n, seed)).reshape(shape)
+        leaf = name.rsplit(".", 1)[-1]
+        if ".norm" in name or "after_norm" in name:
+            t = (1.0 + 0.2 * u) if leaf == "weight" else 0.1 * u
+        elif leaf == "bias":
+            t = 0.1 * u
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            t = u * float(1.0 / np.sqrt(fan_in))
+        out[name] = t.to(torch.float32).contiguous()
+    return out
+
+
 def recipe_wave(name: str, batch: int, n: int, seed: int = 0, amp: float = 0.1) -> np.ndarray:
     """Deterministic synthetic input waveforms [batch, n] float32 in [-amp, amp)."""
     return (philox_uniform(f"wave:{name}", batch * n, seed) * np.float32(amp)).reshape(batch, n)

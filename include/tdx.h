@@ -162,6 +162,22 @@ int tdx_pfenc_forward(tdx_pfenc* h, const float* feats_dev, const int* lens_host
                       float* out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * a10 ERes2NetV2-w24s4ep4 speaker embedding — replaces
+ *     `self.embedding[embedding_model](wav_file, output_emb=True)['embs']`  TargetASR.py:161
+ *     (modelscope / 3D-Speaker ERes2NetV2: third-party).  blob: TDXW container with the
+ *     3D-Speaker module names (conv1, bn1, layer{1..4}.{i}.*, layer3_ds, fuse34, seg_1).
+ *     feat_dev [B,F,80] = tdx_fbank mode-0 output (mean-normalised fbank) -> emb_dev [B,192].
+ *     All B utterances share F (bucket by length); F >= 9.
+ * ---------------------------------------------------------------------------------- */
+typedef struct tdx_eres2net tdx_eres2net;
+int tdx_eres2net_create(const void* weights_blob, size_t blob_bytes, int device, tdx_eres2net** out);
+int tdx_eres2net_destroy(tdx_eres2net* h);
+size_t tdx_eres2net_workspace_bytes(const tdx_eres2net* h, int B, int F);
+double tdx_eres2net_flops(const tdx_eres2net* h, int B, int F);
+int tdx_eres2net_forward(tdx_eres2net* h, const float* feat_dev, int B, int F, float* emb_dev,
+                         void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * a11  cosine scoring — replaces TargetASR.cosine_similarity  TargetASR.py:144-152
  *      emb_dev [N,D] f32, ref_dev [D] f32 -> scores_dev [N] f32 (1.0 if either vector is
  *      all-zero, else cos clipped to [0,1]).

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtdx.so")
-SOURCES = ["mf2.hip", "frontend.hip", "paraformer.hip"]
+SOURCES = ["mf2.hip", "frontend.hip", "paraformer.hip", "eres2net.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 

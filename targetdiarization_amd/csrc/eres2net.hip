@@ -1,0 +1,408 @@
+// eres2net.hip — ERes2NetV2-w24s4ep4 speaker-embedding extractor on MI355X.
+// Replaces `self.embedding['eres2netv2_large'](wav, output_emb=True)['embs']` (TargetASR.py:161;
+// modelscope / 3D-Speaker: third-party, parity unpinned — oracle/eres2netv2_oracle.py).
+// feat [B,F,80] (fbank minus utterance mean, tdx_fbank mode 0) -> embedding [B,192].
+//
+// Layout: NHWC fp32, rows = (b, freq, time), channels contiguous and padded to a multiple of
+// 32.  Every convolution is an implicit GEMM on the fp32-MFMA core (gemm.hpp CONV mode: one
+// K segment per tap, the A-loader computes the shifted/strided input row and zero-fills the
+// halo), with eval-mode BatchNorm folded into the weights on the host and ReLU20 / residual /
+// Res2Net chain add / AFF gate fused into the epilogues.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "../../include/tdx.h"
+#include "gemm.hpp"
+#include "devutil.hpp"
+#include "tdx_common.hpp"
+
+using namespace tdx;
+
+namespace {
+
+constexpr int NSTAGE = 4, SCALE = 4, EMB = 192;
+const int kBlocks[NSTAGE] = {3, 4, 6, 3};
+const int kPlanes[NSTAGE] = {64, 128, 256, 512};
+const int kStride[NSTAGE] = {1, 2, 2, 2};
+
+inline size_t al(size_t n) { return (n + 63) / 64 * 64; }
+inline int up(int n, int m) { return (n + m - 1) / m * m; }
+
+#define LAUNCH_CHECK()                                    \
+    do {                                                  \
+        hipError_t e__ = hipGetLastError();               \
+        if (e__ != hipSuccess) return tdx::fail_hip(e__, __FILE__, __LINE__); \
+    } while (0)
+#define TRY(x) do { int rc__ = (x); if (rc__ != TDX_OK) return rc__; } while (0)
+
+__device__ __forceinline__ float relu20(float v) { return fminf(fmaxf(v, 0.f), 20.f); }
+
+// stem: conv3x3(1->64, pad 1) + BN + ReLU on x[b, h=freq, w=time] = feat[b, w, h]
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ feat, const float* __restrict__ w9,   // [9][64]
+                                                    const float* __restrict__ bias, float* __restrict__ out, int F, long rows) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;     // (row, channel quad): 16 quads per row
+    if (i >= rows * 16) return;
+    const long m = i >> 4;
+    const int c = (int)(i & 15) * 4;
+    const int w = (int)(m % F), h = (int)((m / F) % 80), b = (int)(m / ((long)F * 80));
+    float4 acc = *reinterpret_cast<const float4*>(bias + c);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int ih = h + t / 3 - 1, iw = w + t % 3 - 1;
+        if (ih >= 0 && ih < 80 && iw >= 0 && iw < F) {
+            const float x = feat[((long)b * F + iw) * 80 + ih];
+            const float4 k = *reinterpret_cast<const float4*>(w9 + t * 64 + c);
+            acc.x = fmaf(k.x, x, acc.x); acc.y = fmaf(k.y, x, acc.y); acc.z = fmaf(k.z, x, acc.z); acc.w = fmaf(k.w, x, acc.w);
+        }
+    }
+    acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+    *reinterpret_cast<float4*>(out + m * 64 + c) = acc;
+}
+
+// TSTP over time: x [B, 10, T, 2048] -> stats[b][c*10+fq] (mean) , stats[b][20480 + c*10+fq] (std, unbiased)
+__global__ __launch_bounds__(256) void tstp_kernel(const float* __restrict__ x, float* __restrict__ stats, int T, int C, int Fq) {
+    const int fq = blockIdx.x, b = blockIdx.y;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double s = 0.0, q = 0.0;
+        const float* p = x + (((long)b * Fq + fq) * T) * C + c;
+        for (int t = 0; t < T; ++t) { const double v = p[(long)t * C]; s += v; q += v * v; }
+        const double mean = s / T;
+        double var = (q - s * mean) / (T - 1);
+        if (var < 0) var = 0;
+        stats[(long)b * 2 * C * Fq + (long)c * Fq + fq] = (float)mean;
+        stats[(long)b * 2 * C * Fq + (long)C * Fq + (long)c * Fq + fq] = (float)sqrt(var + 1e-7);
+    }
+}
+
+// seg_1: emb[b][n] = bias[n] + stats[b] . W[n]      (K = 40960)
+__global__ __launch_bounds__(256) void seg_kernel(const float* __restrict__ stats, const float* __restrict__ W,
+                                                   const float* __restrict__ bias, float* __restrict__ emb, int K) {
+    __shared__ float red[4];
+    const int n = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float* s = stats + (long)b * K;
+    const float* w = W + (long)n * K;
+    float acc = 0.f;
+    for (int k = tid * 4; k < K; k += 1024) {
+        const float4 a = *reinterpret_cast<const float4*>(s + k);
+        const float4 c = *reinterpret_cast<const float4*>(w + k);
+        acc = fmaf(a.x, c.x, acc); acc = fmaf(a.y, c.y, acc); acc = fmaf(a.z, c.z, acc); acc = fmaf(a.w, c.w, acc);
+    }
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) emb[(long)b * gridDim.x + n] = (red[0] + red[1]) + (red[2] + red[3]) + bias[n];
+}
+
+// ---------------------------------------------------------------- epilogues
+struct EpiRelu20 {      // clamp(v + b, 0, 20), columns < nreal
+    const float* b; float* out; long ld; int nreal;
+    __device__ float col(int, int n) const { return b[n]; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { if (n < nreal) out[(long)m * ld + n] = relu20(v + c); }
+};
+struct EpiBiasG {       // v + b, columns < nreal
+    const float* b; float* out; long ld; int nreal;
+    __device__ float col(int, int n) const { return b ? b[n] : 0.f; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { if (n < nreal) out[(long)m * ld + n] = v + c; }
+};
+struct EpiChain {       // Res2Net chain: sp = relu20(v+b) -> cat[:, coff+n]; next input sp + spx[i+1] -> spin
+    const float* b; float* cat; long ldcat; int coff; int width; int wpad;
+    const float* o1; long ldo1; int next_off; float* spin;      // spin == nullptr: no plain-add successor
+    __device__ float col(int, int n) const { return b[n]; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ void store(int, int m, int n, float v, EpiNone, float c) const {
+        if (n >= wpad) return;
+        const float sp = relu20(v + c);
+        if (n < width) cat[(long)m * ldcat + coff + n] = sp;
+        if (spin) spin[(long)m * wpad + n] = n < width ? sp + o1[(long)m * ldo1 + next_off + n] : 0.f;
+    }
+};
+struct EpiConv3 {       // relu20(v + b + residual)
+    const float* b; const float* res; float* out; long ld;
+    __device__ float col(int, int n) const { return b[n]; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ void store(int, int m, int n, float v, EpiNone, float c) const {
+        const long i = (long)m * ld + n;
+        out[i] = relu20(v + c + res[i]);
+    }
+};
+struct EpiAffSilu {     // t = silu(v + b), columns < ipad
+    const float* b; float* t; int ipad;
+    __device__ float col(int, int n) const { return b[n]; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { if (n < ipad) t[(long)m * ipad + n] = siluf_acc(v + c); }
+};
+struct EpiAffGate {     // att = 1 + tanh(v+b); out = x*att + y*(2-att), columns < C
+    const float* b; const float* x; long ldx; const float* y; long ldy; float* out; long ldo; int C;
+    __device__ float col(int, int n) const { return b[n]; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ void store(int, int m, int n, float v, EpiNone, float c) const {
+        if (n >= C) return;
+        const float att = 1.0f + tanhf(v + c);
+        out[(long)m * ldo + n] = x[(long)m * ldx + n] * att + y[(long)m * ldy + n] * (2.0f - att);
+    }
+};
+
+struct ConvW { size_t w, b; int N, Npad, cin, cinp, taps; };
+struct AffW { ConvW c0, c3; int C, inter, ipad; };
+struct BlockW { ConvW conv1, convs[4], conv3, sc; bool has_sc; AffW aff[3]; int stride, cin, width, wpad, w4, cout; bool is_aff; };
+
+template <class Epi>
+int conv_gemm(const float* A, long lda, const float* dev, const ConvW& cw, int B, int Hin, int Win, int Hout, int Wout, int stride,
+              Epi e, hipStream_t st) {
+    const long M = (long)B * Hout * Wout;
+    GemmArgs g = make_args((int)M, cw.Npad, make_seg(A, lda, dev + cw.w, (long)cw.taps * cw.cinp, cw.cinp));
+    g.cv_Hin = Hin; g.cv_Win = Win; g.cv_Hout = Hout; g.cv_Wout = Wout; g.cv_stride = stride; g.cv_ntaps = cw.taps; g.cv_cin = cw.cinp;
+    if (launch_gemm<false, false, false, false, Epi, 0, true>(g, 1, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    return TDX_OK;
+}
+
+}  // namespace
+
+struct tdx_eres2net {
+    float* dev; std::vector<BlockW> blocks; size_t stem_w, stem_b, seg_w, seg_b; ConvW ds; AffW fuse34;
+};
+
+namespace {
+
+// AFF(x, y): GEMM1 over the two K segments [x | y], GEMM2 with the gate epilogue
+int run_aff(const tdx_eres2net* h, const AffW& a, const float* x, long ldx, const float* y, long ldy, float* tbuf, float* out, long ldo,
+            long M, hipStream_t st) {
+    {
+        GemmSeg s0 = make_seg(x, ldx, h->dev + a.c0.w, 2L * a.C, a.C);
+        GemmSeg s1 = make_seg(y, ldy, h->dev + a.c0.w + a.C, 2L * a.C, a.C);
+        GemmArgs g = make_args((int)M, a.c0.Npad, s0);
+        g.seg[1] = s1; g.nseg = 2;
+        if (launch_gemm<false, false, false, false>(g, 1, EpiAffSilu{h->dev + a.c0.b, tbuf, a.ipad}, st) != hipSuccess)
+            return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    }
+    GemmArgs g = make_args((int)M, a.c3.Npad, make_seg(tbuf, a.ipad, h->dev + a.c3.w, a.ipad, a.ipad));
+    if (launch_gemm<false, false, false, false>(g, 1, EpiAffGate{h->dev + a.c3.b, x, ldx, y, ldy, out, ldo, a.C}, st) != hipSuccess)
+        return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    return TDX_OK;
+}
+
+struct Dims { int H[5], W[5]; };
+inline Dims make_dims(int F) {
+    Dims d; d.H[0] = 80; d.W[0] = F;
+    for (int s = 0; s < NSTAGE; ++s) {
+        d.H[s + 1] = kStride[s] == 1 ? d.H[s] : (d.H[s] - 1) / 2 + 1;
+        d.W[s + 1] = kStride[s] == 1 ? d.W[s] : (d.W[s] - 1) / 2 + 1;
+    }
+    return d;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tdx_eres2net_create(const void* blob, size_t blob_bytes, int device, tdx_eres2net** out) {
+    if (!blob || !out) return tdx::fail(TDX_E_INVALID, "tdx_eres2net_create: null argument");
+    tdx::Blob bl;
+    if (!bl.parse(blob, blob_bytes)) return tdx::fail(TDX_E_BLOB, "tdx_eres2net_create: malformed TDXW blob");
+    std::vector<float> host;
+    bool ok = true; std::string missing;
+    auto get = [&](const std::string& name, size_t n) -> const float* {
+        const tdx::BlobTensor* t = bl.find(name);
+        if (!t || t->numel != n) { ok = false; if (missing.empty()) missing = name; return nullptr; }
+        return t->data;
+    };
+    // conv [N,Cin,kh,kw] (+bias) followed by eval BatchNorm `bn` ("" = none) -> [Npad][taps][cinp], bias[Npad]
+    auto fold = [&](const std::string& wname, const std::string& bname, const std::string& bn, int N, int cin, int taps) -> ConvW {
+        ConvW cw; cw.N = N; cw.Npad = up(N, 128); cw.cin = cin; cw.cinp = up(cin, 32); cw.taps = taps;
+        const float* W = get(wname, (size_t)N * cin * taps);
+        const float* cb = bname.empty() ? nullptr : get(bname, N);
+        const float *g = nullptr, *be = nullptr, *mu = nullptr, *var = nullptr;
+        if (!bn.empty()) { g = get(bn + "weight", N); be = get(bn + "bias", N); mu = get(bn + "running_mean", N); var = get(bn + "running_var", N); }
+        cw.w = host.size(); host.resize(host.size() + al((size_t)cw.Npad * taps * cw.cinp), 0.f);
+        cw.b = host.size(); host.resize(host.size() + al(cw.Npad), 0.f);
+        if (!ok) return cw;
+        for (int n = 0; n < N; ++n) {
+            const double sc = bn.empty() ? 1.0 : (double)g[n] / sqrt((double)var[n] + 1e-5);
+            const double b0 = cb ? (double)cb[n] : 0.0;
+            host[cw.b + n] = (float)(bn.empty() ? b0 : (b0 - (double)mu[n]) * sc + (double)be[n]);
+            for (int c = 0; c < cin; ++c)
+                for (int t = 0; t < taps; ++t)
+                    host[cw.w + ((size_t)n * taps + t) * cw.cinp + c] = (float)((double)W[((size_t)n * cin + c) * taps + t] * sc);
+        }
+        return cw;
+    };
+    auto fold_aff = [&](const std::string& p, int C) -> AffW {
+        AffW a; a.C = C; a.inter = C / 4; a.ipad = up(a.inter, 32);
+        a.c0 = fold(p + "local_att.0.weight", p + "local_att.0.bias", p + "local_att.1.", a.inter, 2 * C, 1);
+        a.c3 = fold(p + "local_att.3.weight", p + "local_att.3.bias", p + "local_att.4.", C, a.inter, 1);
+        return a;
+    };
+    tdx_eres2net* h = new tdx_eres2net();
+    // stem: [64,1,3,3] + bn1 -> w9[9][64], bias[64]
+    {
+        const float* W = get("conv1.weight", 64 * 9);
+        const float *g = get("bn1.weight", 64), *be = get("bn1.bias", 64), *mu = get("bn1.running_mean", 64), *var = get("bn1.running_var", 64);
+        h->stem_w = host.size(); host.resize(host.size() + al(9 * 64), 0.f);
+        h->stem_b = host.size(); host.resize(host.size() + al(64), 0.f);
+        if (ok) for (int n = 0; n < 64; ++n) {
+            const double sc = (double)g[n] / sqrt((double)var[n] + 1e-5);
+            host[h->stem_b + n] = (float)((double)be[n] - (double)mu[n] * sc);
+            for (int t = 0; t < 9; ++t) host[h->stem_w + t * 64 + n] = (float)((double)W[n * 9 + t] * sc);
+        }
+    }
+    int in_planes = 64;
+    for (int s = 0; s < NSTAGE && ok; ++s) {
+        const int planes = kPlanes[s], width = planes * 24 / 64, cout = planes * 4;
+        for (int i = 0; i < kBlocks[s] && ok; ++i) {
+            const std::string p = "layer" + std::to_string(s + 1) + "." + std::to_string(i) + ".";
+            BlockW b;
+            b.stride = i == 0 ? kStride[s] : 1; b.cin = in_planes; b.width = width; b.wpad = up(width, 32); b.w4 = width * SCALE;
+            b.cout = cout; b.is_aff = s >= 2;
+            b.conv1 = fold(p + "conv1.weight", "", p + "bn1.", b.w4, in_planes, 1);
+            for (int j = 0; j < SCALE; ++j) b.convs[j] = fold(p + "convs." + std::to_string(j) + ".weight", "", p + "bns." + std::to_string(j) + ".", width, width, 9);
+            b.conv3 = fold(p + "conv3.weight", "", p + "bn3.", cout, b.w4, 1);
+            b.has_sc = (b.stride != 1) || (in_planes != cout);
+            if (b.has_sc) b.sc = fold(p + "shortcut.0.weight", "", p + "shortcut.1.", cout, in_planes, 1);
+            if (b.is_aff) for (int j = 0; j < SCALE - 1; ++j) b.aff[j] = fold_aff(p + "fuse_models." + std::to_string(j) + ".", width);
+            h->blocks.push_back(b);
+            in_planes = cout;
+        }
+    }
+    if (ok) {
+        h->ds = fold("layer3_ds.weight", "", "", 2048, 1024, 9);
+        h->fuse34 = fold_aff("fuse34.", 2048);
+        h->seg_w = host.size(); host.resize(host.size() + al((size_t)EMB * 40960), 0.f);
+        const float* sw = get("seg_1.weight", (size_t)EMB * 40960);
+        if (sw) memcpy(host.data() + h->seg_w, sw, (size_t)EMB * 40960 * sizeof(float));
+        h->seg_b = host.size(); host.resize(host.size() + al(EMB), 0.f);
+        const float* sb = get("seg_1.bias", EMB);
+        if (sb) memcpy(host.data() + h->seg_b, sb, EMB * sizeof(float));
+    }
+    if (!ok) { delete h; return tdx::fail(TDX_E_BLOB, "tdx_eres2net_create: tensor missing or wrong size: " + missing); }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) { delete h; return tdx::fail_hip(e, __FILE__, __LINE__); }
+    e = hipMalloc(&h->dev, host.size() * sizeof(float));
+    if (e != hipSuccess) { delete h; return tdx::fail_hip(e, __FILE__, __LINE__); }
+    e = hipMemcpy(h->dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(h->dev); delete h; return tdx::fail_hip(e, __FILE__, __LINE__); }
+    *out = h;
+    return TDX_OK;
+}
+
+int tdx_eres2net_destroy(tdx_eres2net* h) {
+    if (h) { if (h->dev) hipFree(h->dev); delete h; }
+    return TDX_OK;
+}
+
+namespace {
+struct WsPlan { size_t P, keep3, o1, spin, tbuf, stats, total; };
+inline WsPlan ws_plan(const tdx_eres2net* h, int B, int F) {
+    const Dims d = make_dims(F);
+    WsPlan w{}; size_t mP = (size_t)B * 80 * F * 64, mo1 = 0, msp = 0, mt = 0;
+    int s = 0, cnt = 0;
+    for (const BlockW& b : h->blocks) {
+        const size_t rows = (size_t)B * d.H[s + 1] * d.W[s + 1];
+        mP = std::max(mP, rows * b.cout); mo1 = std::max(mo1, rows * b.w4); msp = std::max(msp, rows * b.wpad);
+        if (b.is_aff) mt = std::max(mt, rows * (size_t)b.aff[0].ipad);
+        if (++cnt == kBlocks[s]) { cnt = 0; ++s; }
+    }
+    const size_t rows3 = (size_t)B * d.H[3] * d.W[3], rows4 = (size_t)B * d.H[4] * d.W[4];
+    mt = std::max(mt, rows4 * 512);
+    w.P = al(mP + 4096); w.keep3 = al(rows3 * 1024 + 4096); w.o1 = al(mo1 + 4096); w.spin = al(msp + 4096); w.tbuf = al(mt + 4096);
+    w.stats = al((size_t)B * 40960);
+    w.total = 3 * w.P + w.keep3 + 2 * w.o1 + 2 * w.spin + w.tbuf + w.stats;
+    return w;
+}
+}  // namespace
+
+size_t tdx_eres2net_workspace_bytes(const tdx_eres2net* h, int B, int F) {
+    if (!h || B < 1 || F < 9) return 0;
+    return ws_plan(h, B, F).total * sizeof(float);
+}
+
+double tdx_eres2net_flops(const tdx_eres2net* h, int B, int F) {
+    if (!h || F < 1) return 0.0;
+    const Dims d = make_dims(F);
+    double fl = 2.0 * 80 * F * 9 * 64;
+    int s = 0, cnt = 0;
+    for (const BlockW& b : h->blocks) {
+        const double pos = (double)d.H[s + 1] * d.W[s + 1];
+        fl += 2.0 * pos * ((double)b.cin * b.w4 + 4.0 * 9 * b.width * b.width + (double)b.w4 * b.cout + (b.has_sc ? (double)b.cin * b.cout : 0.0));
+        if (b.is_aff) fl += 3.0 * 2.0 * pos * (2.0 * b.width * (b.width / 4) + (double)(b.width / 4) * b.width);
+        if (++cnt == kBlocks[s]) { cnt = 0; ++s; }
+    }
+    const double pos4 = (double)d.H[4] * d.W[4];
+    fl += 2.0 * pos4 * (9.0 * 1024 * 2048 + 4096.0 * 512 + 512.0 * 2048) + 2.0 * 40960 * EMB;
+    return fl * B;
+}
+
+int tdx_eres2net_forward(tdx_eres2net* h, const float* feat, int B, int F, float* emb, void* ws_, size_t ws_bytes, void* stream) {
+    if (!h || !feat || !emb || !ws_ || B < 1) return tdx::fail(TDX_E_INVALID, "tdx_eres2net_forward: bad argument");
+    if (F < 9) return tdx::fail(TDX_E_INVALID, "tdx_eres2net_forward: need >= 9 fbank frames (TSTP needs >= 2 pooled frames)");
+    const WsPlan wp = ws_plan(h, B, F);
+    if (ws_bytes < wp.total * sizeof(float)) return tdx::fail(TDX_E_WORKSPACE, "tdx_eres2net_forward: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const Dims d = make_dims(F);
+    const size_t rows1 = (size_t)B * 80 * F;
+    float* ws = (float*)ws_;
+    float* P[3] = {ws, ws + wp.P, ws + 2 * wp.P};
+    float* keep3 = ws + 3 * wp.P;
+    float* o1 = keep3 + wp.keep3; float* cat = o1 + wp.o1;
+    float* spin[2] = {cat + wp.o1, cat + wp.o1 + wp.spin};
+    float* tbuf = spin[1] + wp.spin; float* stats = tbuf + wp.tbuf;
+
+    hipLaunchKernelGGL(stem_kernel, dim3((unsigned)((rows1 * 16 + 255) / 256)), dim3(256), 0, st, feat, h->dev + h->stem_w, h->dev + h->stem_b, P[0], F, (long)rows1);
+    LAUNCH_CHECK();
+    const float* x = P[0];
+    int cur = 0;                 // index of the P buffer holding x, or -1 when x is keep3
+    int s = 0, cnt = 0;
+    for (const BlockW& b : h->blocks) {
+        const int Hin = (cnt == 0) ? d.H[s] : d.H[s + 1], Win = (cnt == 0) ? d.W[s] : d.W[s + 1];
+        const int Ho = d.H[s + 1], Wo = d.W[s + 1];
+        const long M = (long)B * Ho * Wo;
+        const bool last_of_stage3 = (s == 2) && (cnt == kBlocks[2] - 1);
+        const int iy = cur < 0 ? 0 : (cur + 1) % 3, ir = cur < 0 ? 1 : (cur + 2) % 3;
+        float* y = last_of_stage3 ? keep3 : P[iy];
+        float* res = P[ir];
+        // conv1 (1x1, stride) + bn1 + relu20 -> o1 [M, w4]
+        TRY(conv_gemm(x, b.cin, h->dev, b.conv1, B, Hin, Win, Ho, Wo, b.stride, EpiRelu20{h->dev + b.conv1.b, o1, b.w4, b.w4}, st));
+        const float* resid = x;
+        if (b.has_sc) {
+            TRY(conv_gemm(x, b.cin, h->dev, b.sc, B, Hin, Win, Ho, Wo, b.stride, EpiBiasG{h->dev + b.sc.b, res, b.cout, b.cout}, st));
+            resid = res;
+        }
+        // Res2Net chain: conv_j reads in_j (o1 chunk 0 in place, later spin[j&1]) and its epilogue
+        // writes sp_j into cat and, for the plain-add stages, in_{j+1} = sp_j + spx[j+1] into spin[(j+1)&1]
+        for (int j = 0; j < SCALE; ++j) {
+            const float* in = j == 0 ? o1 : spin[j & 1];
+            const long ldin = j == 0 ? b.w4 : b.wpad;
+            const bool plain_next = (j + 1 < SCALE) && !b.is_aff;
+            EpiChain e{h->dev + b.convs[j].b, cat, b.w4, j * b.width, b.width, b.wpad, o1, b.w4, (j + 1) * b.width,
+                       plain_next ? spin[(j + 1) & 1] : nullptr};
+            TRY(conv_gemm(in, ldin, h->dev, b.convs[j], B, Ho, Wo, Ho, Wo, 1, e, st));
+            if (b.is_aff && j + 1 < SCALE)      // in_{j+1} = AFF(sp_j, spx[j+1])
+                TRY(run_aff(h, b.aff[j], cat + j * b.width, b.w4, o1 + (j + 1) * b.width, b.w4, tbuf, spin[(j + 1) & 1], b.wpad, M, st));
+        }
+        {   // conv3 + bn3 + residual + relu20 -> y
+            GemmArgs g = make_args((int)M, b.conv3.Npad, make_seg(cat, b.w4, h->dev + b.conv3.w, b.conv3.cinp, b.conv3.cinp));
+            if (launch_gemm<false, false, false, false>(g, 1, EpiConv3{h->dev + b.conv3.b, resid, y, b.cout}, st) != hipSuccess)
+                return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+        }
+        x = y;
+        cur = last_of_stage3 ? -1 : iy;
+        if (++cnt == kBlocks[s]) { cnt = 0; ++s; }
+    }
+    // layer3_ds (3x3 stride 2) on out3, fuse34 = AFF(out4, out3_ds), TSTP, seg_1
+    const int i_ds = (cur + 1) % 3, i_fu = (cur + 2) % 3;
+    const long M4 = (long)B * d.H[4] * d.W[4];
+    TRY(conv_gemm(keep3, 1024, h->dev, h->ds, B, d.H[3], d.W[3], d.H[4], d.W[4], 2, EpiBiasG{nullptr, P[i_ds], 2048, 2048}, st));
+    TRY(run_aff(h, h->fuse34, x, 2048, P[i_ds], 2048, tbuf, P[i_fu], 2048, M4, st));
+    hipLaunchKernelGGL(tstp_kernel, dim3(d.H[4], B), dim3(256), 0, st, P[i_fu], stats, d.W[4], 2048, d.H[4]);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(seg_kernel, dim3(EMB, B), dim3(256), 0, st, stats, h->dev + h->seg_w, h->dev + h->seg_b, emb, 40960);
+    LAUNCH_CHECK();
+    return TDX_OK;
+}
+
+}  // extern "C"

@@ -64,6 +64,10 @@ struct GemmArgs {
     //  map_mode 1: batched small GEMMs, 1-D grid: XCD x owns batches z = 8*j + x, so all tiles
     //              of a batch (which share its operands) hit one L2.
     int map_mode, mp, gw, batches;
+    // CONV (implicit GEMM, NHWC): output row m = (b, h, w) over [B, Hout, Wout]; K segment `tap`
+    // reads input row (b, h*stride+dy, w*stride+dx) of A = [B*Hin*Win, lda] (zero outside), with
+    // (dy,dx) = (tap/3-1, tap%3-1) for 9 taps or (0,0) for 1; weights B = [N][ntaps*cin].
+    int cv_Hin, cv_Win, cv_Hout, cv_Wout, cv_stride, cv_ntaps, cv_cin;
     int pair_off;     // PAIRED: column offset of the second member of a pair
     int shift_k;      // SHIFT: k < shift_k is read from row m-1 (zero when m % shift_S == 0)
     int shift_S;
@@ -104,7 +108,7 @@ struct StageAddr {
 
 // VARIANT != 0 are timing-only diagnostic builds reachable through tdx_linear_variant
 // (1: no global loads inside the k-loop, 2: no barriers) — results are wrong by design.
-template <bool A_KMAJOR, bool B_KMAJOR, bool PAIRED, bool SHIFT, class Epi, int VARIANT = 0>
+template <bool A_KMAJOR, bool B_KMAJOR, bool PAIRED, bool SHIFT, class Epi, int VARIANT = 0, bool CONV = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
     constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = GEMM_BK, P = GEMM_PITCH;
     constexpr int A_ELEMS = A_KMAJOR ? BK * BM : BM * P;
@@ -153,17 +157,35 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, E
     const int ml0 = wm * 64 + l31, ml1 = ml0 + 32;
     const int nl0 = wn * 32 + l31, nl1 = nl0 + 64;
 
-    for (int s = 0; s < g.nseg; ++s) {
-        const bool s0 = s == 0;
+    // CONV: decode this thread's four staging rows once
+    int cvb0 = 0, cvb1 = 0, cvb2 = 0, cvb3 = 0, cvh0 = 0, cvh1 = 0, cvh2 = 0, cvh3 = 0, cvw0 = 0, cvw1 = 0, cvw2 = 0, cvw3 = 0;
+    if constexpr (CONV) {
+#define TDX_CV_DECODE(i, cvb, cvh, cvw)                                  \
+        {                                                                \
+            const int m = min(m0 + ((i) >> 3), g.M - 1);                 \
+            const int hw = g.cv_Hout * g.cv_Wout;                        \
+            const int b_ = m / hw, r_ = m - b_ * hw;                     \
+            const int h_ = r_ / g.cv_Wout, w_ = r_ - h_ * g.cv_Wout;     \
+            cvb = b_ * g.cv_Hin * g.cv_Win; cvh = h_ * g.cv_stride; cvw = w_ * g.cv_stride; \
+        }
+        TDX_CV_DECODE(i0, cvb0, cvh0, cvw0) TDX_CV_DECODE(i1, cvb1, cvh1, cvw1)
+        TDX_CV_DECODE(i2, cvb2, cvh2, cvw2) TDX_CV_DECODE(i3, cvb3, cvh3, cvw3)
+#undef TDX_CV_DECODE
+    }
+    const int nseg = CONV ? g.cv_ntaps : g.nseg;
+
+    for (int s = 0; s < nseg; ++s) {
+        const bool s0 = CONV ? true : s == 0;
         const int zdiv = s0 ? g.seg[0].zdiv : g.seg[1].zdiv;
         const int z1 = z / zdiv, z2 = z - z1 * zdiv;
         const float* __restrict__ Ag = (s0 ? g.seg[0].A : g.seg[1].A) + (long)z1 * (s0 ? g.seg[0].strideA : g.seg[1].strideA) +
                                        (long)z2 * (s0 ? g.seg[0].strideA2 : g.seg[1].strideA2);
         const float* __restrict__ Bg = (s0 ? g.seg[0].B : g.seg[1].B) + (long)z1 * (s0 ? g.seg[0].strideB : g.seg[1].strideB) +
-                                       (long)z2 * (s0 ? g.seg[0].strideB2 : g.seg[1].strideB2);
+                                       (long)z2 * (s0 ? g.seg[0].strideB2 : g.seg[1].strideB2) + (CONV ? s * g.cv_cin : 0);
         const long lda = s0 ? g.seg[0].lda : g.seg[1].lda, ldb = s0 ? g.seg[0].ldb : g.seg[1].ldb;
-        const int K = s0 ? g.seg[0].K : g.seg[1].K;
+        const int K = CONV ? g.cv_cin : (s0 ? g.seg[0].K : g.seg[1].K);
         const int nkt = K / BK;
+        const int cdy = (CONV && g.cv_ntaps == 9) ? s / 3 - 1 : 0, cdx = (CONV && g.cv_ntaps == 9) ? s - (s / 3) * 3 - 1 : 0;
         const int kvalid = min(K, max(0, (s0 ? g.seg[0].ktotal : g.seg[1].ktotal) - z2 * (s0 ? g.seg[0].kchunk : g.seg[1].kchunk)));
 
         // ---- per-thread source addresses for k-tile 0 and validity ----
@@ -171,6 +193,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, E
         const float *pas0 = nullptr, *pas1 = nullptr, *pas2 = nullptr, *pas3 = nullptr;   // SHIFT: shifted-row addresses
         bool oka0 = true, oka1 = true, oka2 = true, oka3 = true;          // row guards (K-contiguous A)
         bool oks0 = true, oks1 = true, oks2 = true, oks3 = true;          // SHIFT: validity of the shifted row
+#define TDX_A_ADDR_CV(i, pa, oka, cvb, cvh, cvw)                                           \
+        {                                                                                  \
+            const int ih = cvh + cdy, iw = cvw + cdx;                                      \
+            oka = (m0 + ((i) >> 3) < g.M) && ih >= 0 && ih < g.cv_Hin && iw >= 0 && iw < g.cv_Win; \
+            const int src = oka ? cvb + ih * g.cv_Win + iw : 0;                            \
+            pa = Ag + (long)src * lda + ((i) & 7) * 4;                                     \
+        }
 #define TDX_A_ADDR(i, pa, pas, oka, oks)                                                   \
         if constexpr (!A_KMAJOR) {                                                         \
             const int m = m0 + ((i) >> 3);                                                 \
@@ -184,8 +213,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, E
         } else {                                                                           \
             pa = Ag + m0 + ((i) & 31) * 4;                                                 \
         }
-        TDX_A_ADDR(i0, pa0, pas0, oka0, oks0) TDX_A_ADDR(i1, pa1, pas1, oka1, oks1)
-        TDX_A_ADDR(i2, pa2, pas2, oka2, oks2) TDX_A_ADDR(i3, pa3, pas3, oka3, oks3)
+        if constexpr (CONV) {
+            TDX_A_ADDR_CV(i0, pa0, oka0, cvb0, cvh0, cvw0) TDX_A_ADDR_CV(i1, pa1, oka1, cvb1, cvh1, cvw1)
+            TDX_A_ADDR_CV(i2, pa2, oka2, cvb2, cvh2, cvw2) TDX_A_ADDR_CV(i3, pa3, oka3, cvb3, cvh3, cvw3)
+        } else {
+            TDX_A_ADDR(i0, pa0, pas0, oka0, oks0) TDX_A_ADDR(i1, pa1, pas1, oka1, oks1)
+            TDX_A_ADDR(i2, pa2, pas2, oka2, oks2) TDX_A_ADDR(i3, pa3, pas3, oka3, oks3)
+        }
 #define TDX_B_ADDR(i, pb)                                                                  \
         if constexpr (!B_KMAJOR) {                                                         \
             const int row = (i) >> 3;                                                      \
@@ -278,6 +312,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, E
 #undef TDX_ST_A
 #undef TDX_ST_B
 #undef TDX_A_ADDR
+#undef TDX_A_ADDR_CV
 #undef TDX_B_ADDR
 #undef TDX_LOAD_A
 #undef TDX_LOAD_B
@@ -307,7 +342,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, E
     }
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR, bool PAIRED, bool SHIFT, class Epi, int VARIANT = 0>
+template <bool A_KMAJOR, bool B_KMAJOR, bool PAIRED, bool SHIFT, class Epi, int VARIANT = 0, bool CONV = false>
 inline hipError_t launch_gemm(GemmArgs g, int batches, Epi epi, hipStream_t st) {
     g.tiles_m = (g.M + GEMM_BM - 1) / GEMM_BM;
     g.tiles_n = PAIRED ? g.N / (GEMM_BN / 2) : g.N / GEMM_BN;
@@ -319,6 +354,7 @@ inline hipError_t launch_gemm(GemmArgs g, int batches, Epi epi, hipStream_t st) 
         // N-tiles per sweep: keep the weight slice (gw x 128 rows x Ktot floats) under ~1.5 MB of the 4 MB L2
         long ktot = 0;
         for (int i = 0; i < g.nseg; ++i) ktot += g.seg[i].K;
+        if (CONV) ktot = (long)g.cv_ntaps * g.cv_cin;
         long gw = (1536L * 1024) / (128L * ktot * 4);
         if (gw < 1) gw = 1;
         if (gw > g.tiles_n) gw = g.tiles_n;
@@ -329,7 +365,7 @@ inline hipError_t launch_gemm(GemmArgs g, int batches, Epi epi, hipStream_t st) 
         g.mp = 0; g.gw = 1;
         grid = dim3(8 * ((batches + 7) / 8) * g.tiles_m * g.tiles_n, 1, 1);
     }
-    hipLaunchKernelGGL((gemm_f32_kernel<A_KMAJOR, B_KMAJOR, PAIRED, SHIFT, Epi, VARIANT>), grid, dim3(GEMM_THREADS), 0, st, g, epi);
+    hipLaunchKernelGGL((gemm_f32_kernel<A_KMAJOR, B_KMAJOR, PAIRED, SHIFT, Epi, VARIANT, CONV>), grid, dim3(GEMM_THREADS), 0, st, g, epi);
     return hipGetLastError();
 }
 

@@ -186,6 +186,68 @@ def recipe_paraformer_state_dict(seed: int = 0, num_blocks: int = 50) -> "Ordere
     return out
 
 
+def eres2netv2_param_shapes(m: int = 64, feat_dim: int = 80, emb: int = 192, base_width: int = 24, scale: int = 4,
+                            expansion: int = 4, num_blocks=(3, 4, 6, 3)) -> "OrderedDict[str, tuple]":
+    """3D-Speaker ERes2NetV2 state_dict layout [upstream-recall, SURVEY Appendix B.3]."""
+    s = OrderedDict()
+
+    def bn(p, c):
+        for leaf in ("weight", "bias", "running_mean", "running_var"):
+            s[p + leaf] = (c,)
+
+    def aff(p, c, r=4):
+        inter = c // r
+        s[p + "local_att.0.weight"] = (inter, 2 * c, 1, 1); s[p + "local_att.0.bias"] = (inter,)
+        bn(p + "local_att.1.", inter)
+        s[p + "local_att.3.weight"] = (c, inter, 1, 1); s[p + "local_att.3.bias"] = (c,)
+        bn(p + "local_att.4.", c)
+
+    s["conv1.weight"] = (m, 1, 3, 3); bn("bn1.", m)
+    in_planes = m
+    for li, (nb, stride) in enumerate(zip(num_blocks, (1, 2, 2, 2)), start=1):
+        planes = m * (2 ** (li - 1))
+        width = int(np.floor(planes * (base_width / 64.0)))
+        for i in range(nb):
+            p = f"layer{li}.{i}."
+            st = stride if i == 0 else 1
+            s[p + "conv1.weight"] = (width * scale, in_planes, 1, 1); bn(p + "bn1.", width * scale)
+            for j in range(scale):
+                s[p + f"convs.{j}.weight"] = (width, width, 3, 3); bn(p + f"bns.{j}.", width)
+            s[p + "conv3.weight"] = (planes * expansion, width * scale, 1, 1); bn(p + "bn3.", planes * expansion)
+            if st != 1 or in_planes != planes * expansion:
+                s[p + "shortcut.0.weight"] = (planes * expansion, in_planes, 1, 1); bn(p + "shortcut.1.", planes * expansion)
+            if li >= 3:
+                for j in range(scale - 1):
+                    aff(p + f"fuse_models.{j}.", width)
+            in_planes = planes * expansion
+    s["layer3_ds.weight"] = (m * 8 * expansion, m * 4 * expansion, 3, 3)
+    aff("fuse34.", m * 8 * expansion)
+    s["seg_1.weight"] = (emb, (feat_dim // 8) * m * 8 * expansion * 2)
+    s["seg_1.bias"] = (emb,)
+    return s
+
+
+def recipe_eres2netv2_state_dict(seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    out = OrderedDict()
+    for name, shape in eres2netv2_param_shapes().items():
+        n = int(np.prod(shape))
+        u = torch.from_numpy(philox_uniform("sv:" + name, n, seed)).reshape(shape)
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf == "running_var":
+            t = 1.0 + 0.3 * u
+        elif leaf == "running_mean":
+            t = 0.1 * u
+        elif len(shape) == 1 and leaf == "weight":
+            t = 1.0 + 0.2 * u                      # BatchNorm gamma
+        elif leaf == "bias":
+            t = 0.1 * u
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            t = u * float(np.sqrt(3.0 / fan_in))    # variance-preserving so 16 bottlenecks stay O(1)
+        out[name] = t.to(torch.float32).contiguous()
+    return out
+
+
 def recipe_wave(name: str, batch: int, n: int, seed: int = 0, amp: float = 0.1) -> np.ndarray:
     """Deterministic synthetic input waveforms [batch, n] float32 in [-amp, amp)."""
     return (philox_uniform(f"wave:{name}", batch * n, seed) * np.float32(amp)).reshape(batch, n)

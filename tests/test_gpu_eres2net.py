@@ -1,0 +1,64 @@
+"""-m gpu: ERes2NetV2 embedding extractor vs its oracle (parity unpinned:
+third-party architecture restated from upstream, recipe weights).  North-star tolerance for
+embeddings: 1e-3 cosine; we also hold 1e-4 rel-L2."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+dev = torch.device("cuda:0")
+
+
+def rel_l2(a, b):
+    a = torch.as_tensor(a).double().cpu().reshape(-1); b = torch.as_tensor(b).double().cpu().reshape(-1)
+    return float((a - b).norm() / b.norm())
+
+
+def cosd(a, b):
+    a = torch.as_tensor(a).double().cpu().reshape(-1); b = torch.as_tensor(b).double().cpu().reshape(-1)
+    return 1.0 - float(torch.dot(a, b) / (a.norm() * b.norm()))
+
+
+@pytest.fixture(scope="module")
+def model_and_sd():
+    from targetdiarization_amd.speaker import ERes2NetV2
+    from targetdiarization_amd.weights import recipe_eres2netv2_state_dict
+    sd = recipe_eres2netv2_state_dict(0)
+    return ERes2NetV2(sd, dev), {k: v.double() for k, v in sd.items()}
+
+
+def test_embedding_from_features_vs_oracle(model_and_sd):
+    from oracle import eres2netv2_oracle as eo
+    model, sd64 = model_and_sd
+    for (B, F) in [(1, 9), (2, 17), (1, 101), (3, 64), (2, 198)]:     # odd sizes exercise the stride-2 edges
+        feat = torch.randn(B, F, 80, generator=torch.Generator().manual_seed(F)) * 2.0
+        ref = eo.eres2netv2_forward(feat.double(), sd64)
+        out = model.embed_features(feat.to(dev))
+        assert out.shape == (B, 192)
+        assert rel_l2(out, ref) < 1e-4 and cosd(out, ref) < 1e-3, (B, F, rel_l2(out, ref))
+
+
+def test_wave_to_embedding_and_cosine(model_and_sd, sd2):
+    """wav -> fbank(povey) - mean -> ERes2NetV2, plus the cosine scorer, vs the chained oracles."""
+    from oracle import eres2netv2_oracle as eo
+    from oracle import frontend_oracle as fo
+    from oracle import mossformer2_oracle as orc
+    from targetdiarization_amd.speaker import SpeakerEmbedder
+    from targetdiarization_amd.weights import recipe_eres2netv2_state_dict, recipe_wave
+    model, sd64 = model_and_sd
+    wav = recipe_wave("svwav", 3, 30768)              # female_a.wav length
+    out = model(torch.from_numpy(wav).to(dev)).cpu()
+    refs = []
+    for b in range(3):
+        feat = fo.sv_features(torch.from_numpy(wav[b]).double())
+        refs.append(eo.eres2netv2_forward(feat[None], sd64)[0])
+        assert cosd(out[b], refs[-1]) < 1e-3 and rel_l2(out[b], refs[-1]) < 1e-4
+    se = SpeakerEmbedder(recipe_eres2netv2_state_dict(0), 0)
+    e1 = se.get_speaker_embedding(wav[1])
+    assert e1.shape == (192,) and e1.dtype == np.float32
+    assert rel_l2(e1, refs[1]) < 1e-4
+    embs = se.get_speaker_embeddings([wav[0], wav[1][:16000], wav[2]])
+    assert rel_l2(embs[2], refs[2]) < 1e-4
+    sc = se.cosine_scores(embs, embs[0])
+    for i in range(3):
+        assert abs(sc[i] - orc.cosine_similarity(embs[i], embs[0])) < 1e-5

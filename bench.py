@@ -83,6 +83,73 @@ def cpu_baseline(sd, wave_np, budget_windows: int):
                       f"(the reference's own batch size), oracle/mossformer2_oracle.py, torch CPU fp32, {dt:.1f}s wall"}
 
 
+def pipeline_bench(args):
+    """BASELINE configs[2]/[3] at window granularity, device-resident: every 10 s window goes
+    H1 -> (both separated streams) H2 + cosine [-> H3 encoder]; windows are independent units."""
+    from targetdiarization_amd import ops
+    from targetdiarization_amd.paraformer import ParaformerEncoder
+    from targetdiarization_amd.separator import MossFormer2Separator
+    from targetdiarization_amd.speaker import ERes2NetV2
+    from targetdiarization_amd.weights import (recipe_eres2netv2_state_dict, recipe_paraformer_state_dict,
+                                               recipe_state_dict)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    total_s = 600 if args.workload == "cfg3" else 1800
+    T = 160000
+    nwin = total_s // 10
+    sep = MossFormer2Separator(recipe_state_dict(0, 24), device=dev)
+    spk = ERes2NetV2(recipe_eres2netv2_state_dict(0), dev)
+    asr = ParaformerEncoder(recipe_paraformer_state_dict(0, 50), dev) if args.workload == "cfg4" else None
+    wav = torch.from_numpy(synth_mixtures(nwin, T, seed=3 if args.workload == "cfg3" else 4)).to(dev)
+    target = torch.randn(192, device=dev)
+    CH = 20          # windows per launch group
+
+    def step():
+        t_sep = t_spk = t_asr = 0.0
+        for c in range(0, nwin, CH):
+            x = wav[c:c + CH]
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e2 = torch.cuda.Event(enable_timing=True); e3 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = sep(x).reshape(-1, T)                      # [2*CH, T] separated streams
+            e1.record()
+            emb = spk(y)
+            sc = ops.cosine_scores(emb, target)
+            e2.record()
+            if asr is not None:
+                enc = asr(y)                               # all 2*CH streams of the group in one launch sequence
+            e3.record()
+            torch.cuda.synchronize()
+            t_sep += e0.elapsed_time(e1); t_spk += e1.elapsed_time(e2); t_asr += e2.elapsed_time(e3)
+        return t_sep, t_spk, t_asr
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    acc = [0.0, 0.0, 0.0]
+    for _ in range(args.steps):
+        r = step()
+        acc = [a + b for a, b in zip(acc, r)]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    S = (T - 16) // 8 + 1
+    F = 1 + (T - 400) // 160
+    fl = {"sep": sep.flops(nwin, T), "spk": spk.flops(2 * nwin, F), "asr": asr.flops(2 * nwin, (F + 5) // 6) if asr else 0.0}
+    line = {"metric": "real-time factor (audio-sec/wall-sec), hot path " + args.workload, "value": total_s * args.steps / dt,
+            "unit": "audio-s/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE {'configs[2]' if args.workload == 'cfg3' else 'configs[3]'}: {total_s} s synthetic audio as "
+                                   f"{nwin} x 10 s windows: MossFormer2 -> ERes2NetV2 on both streams + cosine"
+                                   + (" -> Paraformer encoder on both streams" if asr else "") + ", recipe weights, device-resident"},
+            "stage_ms_per_step": {"separation": acc[0] / args.steps, "embedding+cosine": acc[1] / args.steps, "asr_encoder": acc[2] / args.steps},
+            "stage_tflops": {"separation": fl["sep"] / (acc[0] / args.steps * 1e-3) / 1e12,
+                             "embedding": fl["spk"] / (acc[1] / args.steps * 1e-3) / 1e12,
+                             "asr_encoder": (fl["asr"] / (acc[2] / args.steps * 1e-3) / 1e12) if asr else None},
+            "algorithmic_flops_per_step": fl}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,7 +158,12 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"],
+                    help="cfg2 (default, the headline config): separation only; cfg3: + ERes2NetV2 embeddings + cosine "
+                         "on 10 min of audio; cfg4: + Paraformer encoder on 30 min.  cfg3/cfg4 are extra measurements.")
     args = ap.parse_args()
+    if args.workload != "cfg2":
+        return pipeline_bench(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

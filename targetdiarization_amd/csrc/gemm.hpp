@@ -107,7 +107,7 @@ struct StageAddr {
 };
 
 // VARIANT != 0 are timing-only diagnostic builds reachable through tdx_linear_variant
-// (1: no global loads inside the k-loop, 2: no barriers) — results are wrong by design.
+// (1: no global loads inside the k-loop, 2: no barriers, 3: loads as one burst at the tile start) — results are wrong by design.
 template <bool A_KMAJOR, bool B_KMAJOR, bool PAIRED, bool SHIFT, class Epi, int VARIANT = 0, bool CONV = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, Epi epi) {
     constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = GEMM_BK, P = GEMM_PITCH;
@@ -260,6 +260,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, E
         TDX_LOAD_B(kt, rb0, vb0, pb0, kr0) TDX_LOAD_B(kt, rb1, vb1, pb1, kr1)             \
         TDX_LOAD_B(kt, rb2, vb2, pb2, kr2) TDX_LOAD_B(kt, rb3, vb3, pb3, kr3)
 
+#define TDX_LOAD_PART0(kt) TDX_LOAD_A(kt, ra0, va0, pa0, pas0, oka0, oks0, kr0) TDX_LOAD_B(kt, rb0, vb0, pb0, kr0)
+#define TDX_LOAD_PART1(kt) TDX_LOAD_A(kt, ra1, va1, pa1, pas1, oka1, oks1, kr1) TDX_LOAD_B(kt, rb1, vb1, pb1, kr1)
+#define TDX_LOAD_PART2(kt) TDX_LOAD_A(kt, ra2, va2, pa2, pas2, oka2, oks2, kr2) TDX_LOAD_B(kt, rb2, vb2, pb2, kr2)
+#define TDX_LOAD_PART3(kt) TDX_LOAD_A(kt, ra3, va3, pa3, pas3, oka3, oks3, kr3) TDX_LOAD_B(kt, rb3, vb3, pb3, kr3)
         TDX_LOAD_TILE(0)
         for (int kt = 0; kt < nkt; ++kt) {
             if (VARIANT != 2) __syncthreads();          // previous tile fully consumed
@@ -272,9 +276,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, E
             *reinterpret_cast<f32x4*>(Bs + sb2) = sel4(vb2, rb2);
             *reinterpret_cast<f32x4*>(Bs + sb3) = sel4(vb3, rb3);
             if (VARIANT != 2) __syncthreads();
-            if (VARIANT != 1 && kt + 1 < nkt) {       // next tile's loads stay in flight during the MFMA phase
-                TDX_LOAD_TILE(kt + 1)
-            }
+            // next tile's loads are spread over the MFMA phase (2 x 16 B per lane after each group of
+            // 16 MFMAs) instead of a 32 KB burst per block at the tile boundary
+            const bool more = VARIANT != 1 && kt + 1 < nkt;
+            if (VARIANT == 3 && more) { TDX_LOAD_TILE(kt + 1) }
 #pragma unroll
             for (int kc = 0; kc < BK / 8; ++kc) {
                 f32x4 a0, a1, b0, b1;
@@ -305,6 +310,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, E
                     acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc10, 0, 0, 0);
                     acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc11, 0, 0, 0);
                 }
+                if (VARIANT != 3 && more) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kc == 0) { TDX_LOAD_PART0(kt + 1) }
+                    else if (kc == 1) { TDX_LOAD_PART1(kt + 1) }
+                    else if (kc == 2) { TDX_LOAD_PART2(kt + 1) }
+                    else { TDX_LOAD_PART3(kt + 1) }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         __syncthreads();   // before the next segment overwrites LDS
@@ -317,6 +330,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, E
 #undef TDX_LOAD_A
 #undef TDX_LOAD_B
 #undef TDX_LOAD_TILE
+#undef TDX_LOAD_PART0
+#undef TDX_LOAD_PART1
+#undef TDX_LOAD_PART2
+#undef TDX_LOAD_PART3
 
     // ---- epilogue: D col = l31, row = (r&3) + 8*(r>>2) + 4*h ----
     // per-column constants (bias, gain ...) are fetched once per lane, per-row ones once per row

@@ -801,6 +801,7 @@ int tdx_linear_variant(const float* a, const float* w, int M, int N, int K, floa
     hipError_t r;
     if (variant == 1) r = launch_gemm<false, false, false, false, EpiStore, 1>(g, 1, e, (hipStream_t)stream);
     else if (variant == 2) r = launch_gemm<false, false, false, false, EpiStore, 2>(g, 1, e, (hipStream_t)stream);
+    else if (variant == 3) r = launch_gemm<false, false, false, false, EpiStore, 3>(g, 1, e, (hipStream_t)stream);
     else r = launch_gemm<false, false, false, false, EpiStore, 0>(g, 1, e, (hipStream_t)stream);
     return r == hipSuccess ? TDX_OK : tdx::fail_hip(r, __FILE__, __LINE__);
 }

@@ -311,11 +311,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, E
                     acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc11, 0, 0, 0);
                 }
                 if (VARIANT != 3 && more) {
+                    const int ktn = VARIANT == 4 ? (kt & 1) : kt + 1;     // 4: re-read k-tiles 0/1 (L1/L2-hot) — timing only
                     __builtin_amdgcn_sched_barrier(0);
-                    if (kc == 0) { TDX_LOAD_PART0(kt + 1) }
-                    else if (kc == 1) { TDX_LOAD_PART1(kt + 1) }
-                    else if (kc == 2) { TDX_LOAD_PART2(kt + 1) }
-                    else { TDX_LOAD_PART3(kt + 1) }
+                    if (kc == 0) { TDX_LOAD_PART0(ktn) }
+                    else if (kc == 1) { TDX_LOAD_PART1(ktn) }
+                    else if (kc == 2) { TDX_LOAD_PART2(ktn) }
+                    else { TDX_LOAD_PART3(ktn) }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }

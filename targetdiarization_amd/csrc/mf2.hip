@@ -16,6 +16,7 @@
 
 #include "../../include/tdx.h"
 #include "gemm.hpp"
+#include "gemm_x6.hpp"
 #include "mf2_kernels.hpp"
 #include "tdx_common.hpp"
 
@@ -314,8 +315,16 @@ int ddn_core(const float* p, int B, int S, const float* w1T, const float* w2T, c
     return TDX_OK;
 }
 
+// every nn.Linear / 1x1 Conv1d with a K-contiguous weight goes through the split-bf16 x6 kernel
+// (gemm_x6.hpp); W must be readable up to the next multiple of 256 rows.
 template <class Epi>
 int linear_gemm(const float* A, long lda, const float* W, int M, int N, int K, Epi e, hipStream_t st) {
+    GemmArgs g = make_args(M, N, make_seg(A, lda, W, K, K));
+    if (launch_gemm_x6<false>(g, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    return TDX_OK;
+}
+template <class Epi>
+int linear_gemm_f32(const float* A, long lda, const float* W, int M, int N, int K, Epi e, hipStream_t st) {
     GemmArgs g = make_args(M, N, make_seg(A, lda, W, K, K));
     if (launch_gemm<false, false, false, false>(g, 1, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
     return TDX_OK;
@@ -376,6 +385,7 @@ int tdx_mf2_create(const tdx_mf2_config* cfg, const void* blob, size_t blob_byte
         const float* cwq = get(p + "to_qk.mdl.3.sequential.1.conv.weight", (size_t)QK * 17);
         if (!ok) break;
         o.Whq = push(Wh, (size_t)HID * C); push(Wq, (size_t)QK * C);       // contiguous [2176][512] (HID*C is 64-aligned)
+        host.resize(host.size() + (size_t)128 * C, 0.f);                     // zero rows up to 2304: the x6 GEMM reads W in 256-row tiles
         o.ghq = host.size(); host.resize(host.size() + al(HQ));
         for (int i = 0; i < HQ; ++i) host[o.ghq + i] = i < HID ? gh[0] : gq[0];
         o.bhq = host.size(); host.resize(host.size() + al(HQ));
@@ -604,7 +614,7 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
             EpiHidden e{rs, w.ghq, w.bhq, hid, HQ};
             const bool prof = h->ev_used < h->ev0.size();
             if (prof) hipEventRecord(h->ev0[h->ev_used], st);
-            if (launch_gemm<false, false, false, true>(g, 1, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+            if (launch_gemm_x6<true>(g, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
             if (prof) { hipEventRecord(h->ev1[h->ev_used], st); h->ev_used++; }
         }
         {
@@ -791,7 +801,8 @@ int tdx_dilated_dense_net(const float* p, int B, int S, const float* w1, const f
 int tdx_linear(const float* a, const float* w, const float* bias, int M, int N, int K, float* c, void* stream) {
     if (!a || !w || !c) return tdx::fail(TDX_E_INVALID, "tdx_linear: null argument");
     if (M < 1 || N % 128 || K % 32 || N < 128 || K < 32) return tdx::fail(TDX_E_INVALID, "tdx_linear: need N%128==0, K%32==0");
-    return linear_gemm(a, K, w, M, N, K, EpiBias{bias, c, N}, (hipStream_t)stream);
+    if (N % 256 == 0) return linear_gemm(a, K, w, M, N, K, EpiBias{bias, c, N}, (hipStream_t)stream);     // split-bf16 x6 core
+    return linear_gemm_f32(a, K, w, M, N, K, EpiBias{bias, c, N}, (hipStream_t)stream);                   // fp32-MFMA core
 }
 
 // timing-only diagnostic (not declared in tdx.h): see gemm.hpp VARIANT
@@ -802,6 +813,8 @@ int tdx_linear_variant(const float* a, const float* w, int M, int N, int K, floa
     if (variant == 1) r = launch_gemm<false, false, false, false, EpiStore, 1>(g, 1, e, (hipStream_t)stream);
     else if (variant == 2) r = launch_gemm<false, false, false, false, EpiStore, 2>(g, 1, e, (hipStream_t)stream);
     else if (variant == 3) r = launch_gemm<false, false, false, false, EpiStore, 3>(g, 1, e, (hipStream_t)stream);
+    else if (variant == 4) r = launch_gemm<false, false, false, false, EpiStore, 4>(g, 1, e, (hipStream_t)stream);
+    else if (variant == 6) r = launch_gemm_x6<false>(g, e, (hipStream_t)stream);
     else r = launch_gemm<false, false, false, false, EpiStore, 0>(g, 1, e, (hipStream_t)stream);
     return r == hipSuccess ? TDX_OK : tdx::fail_hip(r, __FILE__, __LINE__);
 }

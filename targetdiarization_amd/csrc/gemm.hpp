@@ -87,6 +87,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 //              void store(int z,int m,int n,float v,Row,Col) const;            // plain
 //              void store2(int z,int m,int c,float v0,float v1,Row,Col) const; // PAIRED }
 struct EpiNone {};
+// optional member  Aux aux(int z,int m,int n,Row) const : a value the epilogue has to LOAD per
+// output element (residual, gate operands ...).  The kernels fetch it for 16 elements at a time
+// before the first store of the batch, so the loads overlap instead of forming a load->store
+// chain per element (stores may alias the loads as far as the compiler can tell).
+template <class E, class = void> struct epi_has_aux { static constexpr bool value = false; };
+template <class E> struct epi_has_aux<E, decltype((void)&E::aux, void())> { static constexpr bool value = true; };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -337,23 +343,53 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, E
 #undef TDX_LOAD_PART3
 
     // ---- epilogue: D col = l31, row = (r&3) + 8*(r>>2) + 4*h ----
-    // per-column constants (bias, gain ...) are fetched once per lane, per-row ones once per row
+    // per-column constants (bias, gain ...) are fetched once per lane; per-row constants and the
+    // per-element auxiliary loads are fetched for 16 rows before the first store of the batch
     const auto c0 = epi.col(z, n0 + nl0);
     const auto c1 = epi.col(z, PAIRED ? n0 + nl0 : n0 + nl1);
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
+        decltype(epi.row(0, 0)) rw[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float v0 = tm == 0 ? acc00[r] : acc10[r];
-            const float v1 = tm == 0 ? acc01[r] : acc11[r];
-            if (m < g.M) {
-                const auto rw = epi.row(z, m);
-                if constexpr (PAIRED) {
-                    epi.store2(z, m, n0 + nl0, v0, v1, rw, c0);
-                } else {
-                    epi.store(z, m, n0 + nl0, v0, rw, c0);
-                    epi.store(z, m, n0 + nl1, v1, rw, c1);
+            const int m = min(m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, g.M - 1);
+            rw[r] = epi.row(z, m);
+        }
+        if constexpr (epi_has_aux<Epi>::value) {
+            decltype(epi.aux(0, 0, 0, rw[0])) ax0[16], ax1[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = min(m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, g.M - 1);
+                ax0[r] = epi.aux(z, m, n0 + nl0, rw[r]);
+                if constexpr (!PAIRED) ax1[r] = epi.aux(z, m, n0 + nl1, rw[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v0 = tm == 0 ? acc00[r] : acc10[r];
+                const float v1 = tm == 0 ? acc01[r] : acc11[r];
+                if (m < g.M) {
+                    if constexpr (PAIRED) {
+                        epi.store2(z, m, n0 + nl0, v0, v1, rw[r], c0, ax0[r]);
+                    } else {
+                        epi.store(z, m, n0 + nl0, v0, rw[r], c0, ax0[r]);
+                        epi.store(z, m, n0 + nl1, v1, rw[r], c1, ax1[r]);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v0 = tm == 0 ? acc00[r] : acc10[r];
+                const float v1 = tm == 0 ? acc01[r] : acc11[r];
+                if (m < g.M) {
+                    if constexpr (PAIRED) {
+                        epi.store2(z, m, n0 + nl0, v0, v1, rw[r], c0);
+                    } else {
+                        epi.store(z, m, n0 + nl0, v0, rw[r], c0);
+                        epi.store(z, m, n0 + nl1, v1, rw[r], c1);
+                    }
                 }
             }
         }

@@ -57,14 +57,17 @@ struct EpiAttnGate { // o = (att_u*v)*sigmoid(att_v*u)                       mos
         const int b = z / G, s = (z % G) * 256 + m;
         return s < S ? (long)b * S + s : -1L;
     }
-    __device__ void store2(int, int, int c, float av, float au, long rw, EpiNone) const {
+    __device__ float2 aux(int, int, int c, long rw) const {       // the gate's v, u operands
+        if (rw < 0 || att_v) return make_float2(0.f, 0.f);
+        return make_float2(vu[rw * (2 * E) + c], vu[rw * (2 * E) + E + c]);
+    }
+    __device__ void store2(int, int, int c, float av, float au, long rw, EpiNone, float2 vu2) const {
         if (rw < 0) return;
         if (att_v) {  // stand-alone cal_attention: return the two attention outputs
             att_v[rw * E + c] = av;
             att_u[rw * E + c] = au;
         } else {
-            const float v = vu[rw * (2 * E) + c], u = vu[rw * (2 * E) + E + c];
-            o[rw * E + c] = (au * v) * sigmoidf_acc(av * u);
+            o[rw * E + c] = (au * vu2.x) * sigmoidf_acc(av * vu2.y);
         }
     }
 };
@@ -92,13 +95,15 @@ struct EpiBias { const float* b; float* out; long ld;   // b may be null
 struct EpiBiasResidual { const float* b; float* x; long ld;   // x += acc + b   mossformer_block.py:424-425
     __device__ float col(int, int n) const { return b[n]; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
-    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { x[(long)m * ld + n] += v + c; } };
+    __device__ float aux(int, int m, int n, EpiNone) const { return x[(long)m * ld + n]; }
+    __device__ void store(int, int m, int n, float v, EpiNone, float c, float xo) const { x[(long)m * ld + n] = xo + (v + c); } };
 struct EpiPosEnc {   // z = acc + pe[s][n]*scale ; x = z                     mossformer2.py:490-496
     const float* pe; const float* scale; float* zout; float* x; int S;
     __device__ float col(int, int) const { return scale[0]; }
     __device__ int row(int, int m) const { return m % S; }
-    __device__ void store(int, int m, int n, float v, int s, float sc) const {
-        const float r = v + pe[(long)s * C + n] * sc;
+    __device__ float aux(int, int, int n, int s) const { return pe[(long)s * C + n]; }
+    __device__ void store(int, int m, int n, float v, int, float sc, float pv) const {
+        const float r = v + pv * sc;
         zout[(long)m * C + n] = r; x[(long)m * C + n] = r;
     }
 };
@@ -114,10 +119,11 @@ struct EpiMaskMul {  // mask = relu(acc); EM = E*mask                        mos
     const float* E; float* EM; float* mask; long strideZ;
     __device__ EpiNone col(int, int) const { return EpiNone{}; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
-    __device__ void store(int z, int m, int n, float v, EpiNone, EpiNone) const {
+    __device__ float aux(int, int m, int n, EpiNone) const { return E[(long)m * C + n]; }
+    __device__ void store(int z, int m, int n, float v, EpiNone, EpiNone, float e) const {
         v = fmaxf(v, 0.f);
         if (mask) mask[(long)z * strideZ + (long)m * C + n] = v;
-        EM[(long)z * strideZ + (long)m * C + n] = v * E[(long)m * C + n];
+        EM[(long)z * strideZ + (long)m * C + n] = v * e;
     }
 };
 
@@ -296,7 +302,10 @@ int attention_core(const float* qk4, const float* vu, int B, int S, int E, int s
         GemmArgs g = make_args(256, E, s0);
         g.seg[1] = s1; g.nseg = 2; g.pair_off = E;
         EpiAttnGate e{vu, o, att_v, att_u, G, S, E};
-        if (launch_gemm<false, true, true, false>(g, B * G, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+        hipError_t r;
+        if (E % 128 == 0) r = launch_gemm_x6<true, true, false>(g, B * G, e, st);       // split-bf16 x6 core (256-row group = one M tile)
+        else r = launch_gemm<false, true, true, false>(g, B * G, e, st);                // fp32-MFMA core (test shapes with E % 128 != 0)
+        if (r != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
     }
     return TDX_OK;
 }

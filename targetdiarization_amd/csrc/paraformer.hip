@@ -98,7 +98,8 @@ struct EpiBiasReluP { const float* b; float* out; long ld;
 struct EpiBiasResP { const float* b; float* x; long ld;
     __device__ float col(int, int n) const { return b[n]; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
-    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { x[(long)m * ld + n] += v + c; } };
+    __device__ float aux(int, int m, int n, EpiNone) const { return x[(long)m * ld + n]; }
+    __device__ void store(int, int m, int n, float v, EpiNone, float c, float xo) const { x[(long)m * ld + n] = xo + (v + c); } };
 struct EpiScores { float* sc; int Sp; float scale;     // q k^T * dk^-0.5 -> [z][Sp][Sp]
     __device__ EpiNone col(int, int) const { return EpiNone{}; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
@@ -111,12 +112,11 @@ struct EpiCtx { float* ctx; int S;                      // head h of batch b -> 
 struct EpiOutProj { const float* b; const float* mem; const float* resid; float* x;   // att W_o + b + fsmn_memory (+ residual)
     __device__ float col(int, int n) const { return b[n]; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
-    __device__ void store(int, int m, int n, float v, EpiNone, float c) const {
+    __device__ float aux(int, int m, int n, EpiNone) const {
         const long i = (long)m * D + n;
-        float r = v + c + mem[i];
-        if (resid) r += resid[i];
-        x[i] = r;
-    } };
+        return resid ? mem[i] + resid[i] : mem[i];
+    }
+    __device__ void store(int, int m, int n, float v, EpiNone, float c, float a) const { x[(long)m * D + n] = (v + c) + a; } };
 
 struct PfLayer { const float *Wqkv, *bqkv, *fsmnT, *Wo, *bo, *W1, *b1, *W2, *b2, *n1g, *n1b, *n2g, *n2b; };
 

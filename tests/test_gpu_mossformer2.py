@@ -64,10 +64,11 @@ def test_cal_attention_golden(gold, sd24, dev):
     av, au = ops.cal_attention(*(t.to(dev) for t in (qq, lq, qk, lk, v, u, freqs)))
     assert rel_l2(av, fx["att_v"]) < 1e-5
     assert rel_l2(au, fx["att_u"]) < 1e-5
-    # ragged / edge sizes vs the oracle: S=1, S=255, S=256, S=257, S=1000
+    # ragged / edge sizes vs the oracle: S=1, S=255, S=256, S=257, S=1000; E=128 goes through the
+    # split-bf16 x6 attention GEMM (as the model's E=1024 does), E=64 through the fp32-MFMA one
     g = torch.Generator().manual_seed(3)
-    for S2 in (1, 255, 256, 257, 1000):
-        ts = [torch.rand(1, S2, 128, generator=g) - 0.5 for _ in range(4)] + [torch.rand(1, S2, 128, generator=g) - 0.5 for _ in range(2)]
+    for S2, E2 in ((1, 128), (255, 128), (256, 64), (257, 128), (1000, 256)):
+        ts = [torch.rand(1, S2, 128, generator=g) - 0.5 for _ in range(4)] + [torch.rand(1, S2, E2, generator=g) - 0.5 for _ in range(2)]
         ov, ou = orc.cal_attention(*[t.double() for t in ts], freqs.double())
         av, au = ops.cal_attention(*(t.to(dev) for t in ts), freqs.to(dev))
         assert rel_l2(av, ov) < 1e-5 and rel_l2(au, ou) < 1e-5, S2

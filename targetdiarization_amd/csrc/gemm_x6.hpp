@@ -130,6 +130,9 @@ __global__ __launch_bounds__(X6_THREADS, 2) void gemm_x6_kernel(GemmArgs g, Epi 
 
     const int mA0 = m0 + r0, mA1 = m0 + r1;
     const bool okA0 = mA0 < g.M, okA1 = mA1 < g.M;
+    // last N tile of a width that is not a multiple of 256: its upper 128 columns (MFMA tile
+    // tn = 1 of every wave) do not exist -> skip those MFMAs (block-uniform branch)
+    const bool full_n = PAIRED || (n0 + 128 < g.N);
 
     for (int s = 0; s < g.nseg; ++s) {
         const bool s0 = s == 0;
@@ -225,6 +228,7 @@ __global__ __launch_bounds__(X6_THREADS, 2) void gemm_x6_kernel(GemmArgs g, Epi 
             for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn) {
+                    if (tn == 1 && !full_n) continue;
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], bl[tn], acc[tm][tn], 0, 0, 0);
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], bmid[tn], acc[tm][tn], 0, 0, 0);
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], bh[tn], acc[tm][tn], 0, 0, 0);
@@ -236,6 +240,7 @@ __global__ __launch_bounds__(X6_THREADS, 2) void gemm_x6_kernel(GemmArgs g, Epi 
             for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn) {
+                    if (tn == 1 && !full_n) continue;
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], bmid[tn], acc[tm][tn], 0, 0, 0);
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], bh[tn], acc[tm][tn], 0, 0, 0);
                 }
@@ -245,8 +250,10 @@ __global__ __launch_bounds__(X6_THREADS, 2) void gemm_x6_kernel(GemmArgs g, Epi 
 #pragma unroll
             for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
+                for (int tn = 0; tn < 2; ++tn) {
+                    if (tn == 1 && !full_n) continue;
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                }
             __syncthreads();
         }
 #undef X6_LOAD

@@ -212,8 +212,9 @@ inline size_t al(size_t n) { return (n + 63) / 64 * 64; }
 bool make_plan(const tdx_mf2* h, int B, int T, Plan& P) {
     if (B < 1 || T < 16) return false;
     P.B = B; P.T = T; P.S = (T - 16) / 8 + 1; P.G = (P.S + 255) / 256; P.Sp = P.G * 256; P.M = (long)B * P.S;
-    // split-K for the linear-attention K^T[v|u] GEMM: aim for >= 512 workgroups
-    int sp = 512 / (16 * B); if (sp < 1) sp = 1;
+    // split-K for the linear-attention K^T[v|u] GEMM (16 N-tiles per sample, 3 blocks per CU
+    // resident): aim for >= 1536 workgroups so that the 256 CUs stay full (slabs are 1 MB each)
+    int sp = (1536 + 16 * B - 1) / (16 * B); if (sp < 1) sp = 1;
     int maxsp = (P.S + 511) / 512; if (sp > maxsp) sp = maxsp;
     P.splits = sp;
     P.kchunk = ((P.S + sp - 1) / sp + 31) / 32 * 32;
@@ -726,7 +727,7 @@ int tdx_mf2_tap(tdx_mf2* h, const char* name, int B, int T, void* ws_, float* ds
 static void attn_plan(int B, int S, int E, int& splits, int& kchunk, size_t& qk4, size_t& vu, size_t& Abuf, size_t& slab, size_t& kvu,
                       size_t& total) {
     const int G = (S + 255) / 256, Sp = G * 256;
-    int sp = 512 / ((2 * E / 128) * B); if (sp < 1) sp = 1;
+    int sp = (1536 + (2 * E / 128) * B - 1) / ((2 * E / 128) * B); if (sp < 1) sp = 1;
     int maxsp = (S + 511) / 512; if (sp > maxsp) sp = maxsp;
     kchunk = ((S + sp - 1) / sp + 31) / 32 * 32;
     splits = (S + kchunk - 1) / kchunk;

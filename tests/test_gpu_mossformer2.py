@@ -174,6 +174,21 @@ def test_full_size_properties(sep24, dev):
     assert torch.count_nonzero(y[..., 64000:]) == 0
 
 
+def test_max_window_and_properties(sep24, dev):
+    """largest window the reference's plan can produce (240 000 samples -> S = 29 999, 118 groups):
+    finite, deterministic, linear in nothing but consistent with the 10 s prefix property NOT holding
+    (the model is sequence-global per window: SURVEY §5) and with batch independence."""
+    from targetdiarization_amd.weights import recipe_wave
+    x = torch.from_numpy(recipe_wave("maxwin", 1, 240000)).to(dev)
+    y = sep24(x)
+    assert y.shape == (1, 2, 240000) and torch.isfinite(y).all()
+    y2 = sep24(torch.cat([x, x.flip(-1)], 0))
+    assert rel_l2(y2[0:1], y) < 1e-5
+    # re-chunking changes the result (global norms / linear attention): guard against silently windowing
+    y10 = sep24(x[:, :160000])
+    assert rel_l2(y[..., :160000], y10) > 1e-3
+
+
 def test_cosine_scores(dev):
     from oracle import mossformer2_oracle as orc
     from targetdiarization_amd import ops

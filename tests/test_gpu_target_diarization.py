@@ -1,0 +1,61 @@
+"""-m gpu: TargetDiarization.infer (N1) end to end on the reference's config-1 assets with
+synthetic segmentation plug-ins (the CAM++/pyannote/FSMN-VAD models are third-party and absent):
+checks the contract of the return value and that the batched hot loops give the same decisions as
+the reference's per-segment loop restated with the oracles' scorer."""
+import os
+import wave as wavmod
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(gold, fn):
+    with wavmod.open(os.path.join(gold, fn), "rb") as w:
+        return np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).astype(np.float32) / 32768.0
+
+
+def test_infer_contract_and_decisions(gold, sd2):
+    from oracle import mossformer2_oracle as orc
+    from targetdiarization_amd import intervals as iv
+    from targetdiarization_amd.target_diarization import TargetDiarization
+    from targetdiarization_amd.weights import recipe_eres2netv2_state_dict, recipe_paraformer_state_dict
+    mix, tgt = _load(gold, "chat_mix.wav"), _load(gold, "female_a.wav")
+    sd_rows = {"text": [[0.0, 3.0, 0], [2.4, 5.5, 1], [5.5, 8.6, 0]]}
+    od = [(0.0, 3.0, "SPEAKER_00"), (2.4, 5.5, "SPEAKER_01"), (5.5, 8.6, "SPEAKER_00")]
+    td = TargetDiarization(cuda_device=0, sep_state_dict=sd2, spk_state_dict=recipe_eres2netv2_state_dict(0),
+                           asr_state_dict=recipe_paraformer_state_dict(0, 2), sd_pipeline=lambda a: sd_rows,
+                           od_pipeline=lambda a: od, target_similarity_threshold=0.0)
+    target_spk, results, target_audio = td.infer(mix, tgt)
+    assert target_spk in ("0", "1")
+    assert results and all(set(r) >= {"speaker", "timerange", "text", "type", "score"} for r in results)
+    assert all("audio" not in r for r in results)
+    assert [r["timerange"][0] for r in results] == sorted(r["timerange"][0] for r in results)
+    assert {r["type"] for r in results} <= {"single", "overlap"}
+    assert any(r["type"] == "overlap" for r in results)            # 2.4-3.0 s is a 0.6 s overlap (>= 0.4 s)
+    assert target_audio is not None and target_audio.dtype == np.float32
+    assert abs(len(target_audio) / 16000 - results[-1]["timerange"][1]) < 0.05
+    # decision of hot loop A restated per segment (reference semantics :581-600) with the host scorer
+    audio = td.audio_preprocess(mix)
+    sd_res = iv.sd_result_parser(sd_rows)
+    od_res = td.od_result_parser(od, sd_result=sd_res)
+    refined, omap = iv.apply_od_result(sd_res, od_res)
+    single = iv.subtract_overlap(refined, omap)
+    temb = td.hp.spk.get_speaker_embedding(td.audio_preprocess(tgt))
+    means = {}
+    for spk, rs in single.items():
+        sc = [orc.cosine_similarity(temb, td.hp.spk.get_speaker_embedding(td.split_audio_by_time(audio, s, e))) for (s, e) in rs]
+        means[spk] = sum(sc) / len(sc)
+    assert target_spk == max(means, key=means.get)
+
+
+def test_infer_single_and_no_target(gold, sd2):
+    from targetdiarization_amd.target_diarization import TargetDiarization
+    from targetdiarization_amd.weights import recipe_eres2netv2_state_dict
+    mix = _load(gold, "chat_mix.wav")
+    td = TargetDiarization(cuda_device=0, sep_state_dict=sd2, spk_state_dict=recipe_eres2netv2_state_dict(0))
+    spk, res, aud = td.infer(mix, None, is_single=True, output_target_audio=False)
+    assert spk == "" and aud is None and len(res) == 1 and res[0]["speaker"] == "0" and res[0]["score"] == -1.0
+    spk2, res2, aud2 = td.infer(mix, None)        # no target file: longest speaker becomes the target
+    assert spk2 == "0" and aud2 is not None

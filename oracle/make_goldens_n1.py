@@ -90,6 +90,73 @@ def main():
                                            "out": ref.sd_result_parser({"text": [list(r) for r in rows]}, single, comb)})
     json.dump(cases, open(os.path.join(ROOT, "tests", "golden", "n1_intervals.json"), "w"))
     print({k: len(v) for k, v in cases.items()})
+    assembly(ref, rng)
+
+
+class _Seg:
+    def __init__(self, s, e):
+        self.start, self.end = s, e
+
+
+class _Annotation:
+    """the only part of pyannote's Annotation that od_result_parser touches (:233)"""
+    def __init__(self, rows):
+        self.rows = rows
+
+    def __bool__(self):
+        return bool(self.rows)
+
+    def itertracks(self, yield_label=True):
+        for i, (s, e, lab) in enumerate(self.rows):
+            yield _Seg(s, e), i, lab
+
+
+def assembly(ref, rng):
+    """combine_audio_chunks (:822), asr_audio_parser (:841), od_result_parser (:230): audio clips are
+    deterministic ramps (value = item index + 1) so the expected timeline is stored run-length coded."""
+    import numpy as np
+
+    def rle(a):
+        if a is None:
+            return None
+        out, i = [], 0
+        while i < len(a):
+            j = i
+            while j < len(a) and a[j] == a[i]:
+                j += 1
+            out.append([float(a[i]), j - i]); i = j
+        return out
+
+    cases = {"combine": [], "asr_parser": [], "od_parser": []}
+    for _ in range(30):
+        n, t, items = rng.randint(0, 7), 0.0, []
+        for i in range(n):
+            s = round(t + rng.uniform(-0.3, 1.0), 3) if i else round(rng.uniform(0, 1.0), 3)
+            s = max(s, 0.0)
+            e = round(s + rng.uniform(0.05, 1.2), 3)
+            alen = int((e - s) * 16000) + rng.choice([0, 0, -7, 13])
+            items.append({"speaker": str(rng.randint(0, 2)), "timerange": [s, e], "text": "", "type": "single", "alen": max(alen, 1)})
+            t = e
+        def mk():
+            return [dict(it, audio=np.full(it["alen"], i + 1, dtype=np.float32)) for i, it in enumerate(items)]
+        for spk in ("0", "1"):
+            cases["combine"].append({"items": items, "spk": spk, "out": rle(ref.combine_audio_chunks(mk(), spk))})
+            for flag in (True, False):
+                res, aud = ref.asr_audio_parser(mk(), spk, flag)
+                cases["asr_parser"].append({"items": items, "spk": spk, "flag": flag, "res": res, "out": rle(aud)})
+    for _ in range(30):
+        rows = []
+        for _ in range(rng.randint(0, 7)):
+            s = rng.uniform(0, 20)
+            rows.append((s, s + rng.uniform(0.2, 5), "SPEAKER_%02d" % rng.randint(0, 2)))
+        sd = {str(k): ref.merge_timeranges(rand_ranges(rng, rng.randint(1, 4), span=20.0)) for k in range(rng.randint(1, 3))}
+        for single in (False, True):
+            for ov in (False, True):
+                for use_sd in (False, True):
+                    out = ref.od_result_parser(_Annotation(rows), {k: list(v) for k, v in sd.items()} if use_sd else {}, single, ov)
+                    cases["od_parser"].append({"rows": rows, "sd": sd if use_sd else {}, "single": single, "ov": ov, "out": out})
+    json.dump(cases, open(os.path.join(ROOT, "tests", "golden", "n1_assembly.json"), "w"))
+    print({k: len(v) for k, v in cases.items()})
 
 
 if __name__ == "__main__":

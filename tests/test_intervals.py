@@ -72,3 +72,37 @@ def test_speaker_num_and_parser(g):
     for c in g["sd_parser"]:
         out = iv.sd_result_parser({"text": [list(r) for r in c["rows"]]}, c["single"], c["comb"])
         assert L(out) == c["out"]
+
+
+def _rle(a):
+    if a is None:
+        return None
+    out, i = [], 0
+    while i < len(a):
+        j = i
+        while j < len(a) and a[j] == a[i]:
+            j += 1
+        out.append([float(a[i]), j - i]); i = j
+    return out
+
+
+def test_assembly_functions_match_reference_goldens():
+    """combine_audio_chunks / asr_audio_parser / od_result_parser of the orchestrator against outputs
+    of the reference's own methods (oracle/make_goldens_n1.py::assembly)."""
+    import numpy as np
+    from targetdiarization_amd.target_diarization import TargetDiarization
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "n1_assembly.json")))
+    td = object.__new__(TargetDiarization)
+
+    def mk(items):
+        return [dict({k: v for k, v in it.items() if k != "alen"}, alen=it["alen"], audio=np.full(it["alen"], i + 1, dtype=np.float32))
+                for i, it in enumerate(items)]
+    for c in g["combine"]:
+        assert _rle(td.combine_audio_chunks(mk(c["items"]), c["spk"])) == c["out"]
+    for c in g["asr_parser"]:
+        res, aud = td.asr_audio_parser(mk(c["items"]), c["spk"], c["flag"])
+        assert _rle(aud) == c["out"]
+        assert json.loads(json.dumps(res)) == c["res"]
+    for c in g["od_parser"]:
+        out = td.od_result_parser([tuple(r) for r in c["rows"]], {k: [tuple(x) for x in v] for k, v in c["sd"].items()}, c["single"], c["ov"])
+        assert json.loads(json.dumps(out)) == c["out"]

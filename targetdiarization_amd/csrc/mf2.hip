@@ -17,6 +17,7 @@
 #include "../../include/tdx.h"
 #include "gemm.hpp"
 #include "gemm_x6.hpp"
+#include "gemm_h3.hpp"
 #include "mf2_kernels.hpp"
 #include "tdx_common.hpp"
 
@@ -826,6 +827,21 @@ int tdx_linear_variant(const float* a, const float* w, int M, int N, int K, floa
     else if (variant == 4) r = launch_gemm<false, false, false, false, EpiStore, 4>(g, 1, e, (hipStream_t)stream);
     else if (variant == 6) r = launch_gemm_x6<false>(g, e, (hipStream_t)stream);
     else r = launch_gemm<false, false, false, false, EpiStore, 0>(g, 1, e, (hipStream_t)stream);
+    return r == hipSuccess ? TDX_OK : tdx::fail_hip(r, __FILE__, __LINE__);
+}
+
+// diagnostics for the split-f16 x3 core (not declared in tdx.h): tools/h3_test.py
+int tdx_h3_split_rows(const float* x, long ld, void* planes, float* scale, long R, int K, void* stream) {
+    if (K % 8 || K > 2048) return tdx::fail(TDX_E_INVALID, "tdx_h3_split_rows: need K%8==0, K<=2048");
+    hipError_t r = tdx::launch_h3_split_rows(x, ld, planes, scale, R, K, (hipStream_t)stream);
+    return r == hipSuccess ? TDX_OK : tdx::fail_hip(r, __FILE__, __LINE__);
+}
+int tdx_h3_gemm(const void* pa, const float* sa, const void* pb, const float* sb, const float* bias, float* c, int M, int N, int K, void* stream) {
+    if (K % 16) return tdx::fail(TDX_E_INVALID, "tdx_h3_gemm: need K%16==0");
+    tdx::H3Args g{};
+    g.seg[0] = tdx::h3_seg(pa, sa, 4L * K, pb, sb, 4L * K, K);
+    g.nseg = 1; g.M = M; g.N = N;
+    hipError_t r = tdx::launch_gemm_h3<false>(g, 1, EpiBias{bias, c, N}, (hipStream_t)stream);
     return r == hipSuccess ? TDX_OK : tdx::fail_hip(r, __FILE__, __LINE__);
 }
 

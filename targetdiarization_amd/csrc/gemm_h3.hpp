@@ -90,7 +90,7 @@ __device__ __forceinline__ void h3_glds16(const unsigned char* g, unsigned char*
 // one pipeline stage: MFMAs of the tile whose fragments are in (ah, al, bh, bl); with NEXT the
 // fragments of the following tile are read from stage buffer `nxt`; with ISSUE the wave's four
 // LDS-DMA pieces of the tile three ahead are issued (src = gp[j] + goff, dst = dmad + j KiB).
-template <bool FULLN, bool NEXT, bool ISSUE>
+template <bool FULLN, bool NEXT, bool ISSUE, int PH>
 __device__ __forceinline__ void h3_stage(f32x16 (&acc)[4][2], f16x8 (&ah)[4], f16x8 (&al)[4], f16x8 (&bh)[2], f16x8 (&bl)[2],
                                          const unsigned char* nxt, int fa, int fb, int fo0, int fo1,
                                          const unsigned char* const (&gp)[4], long goff, unsigned char* dmad) {
@@ -109,16 +109,38 @@ __device__ __forceinline__ void h3_stage(f32x16 (&acc)[4][2], f16x8 (&ah)[4], f1
             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+            if constexpr (ISSUE) {
+                if ((tm >> 1) == PH) h3_glds16(gp[(tm & 1) * 2 + tn] + goff, dmad + ((tm & 1) * 2 + tn) * 1024);
+            }
+        }
+        if constexpr (ISSUE && !FULLN) {
+            if ((tm >> 1) == PH) h3_glds16(gp[(tm & 1) * 2 + 1] + goff, dmad + ((tm & 1) * 2 + 1) * 1024);
         }
         if constexpr (NEXT) {
             ah[tm] = *reinterpret_cast<const f16x8*>(nxt + fa + tm * 32 * H3_ROWB + fo0);
             al[tm] = *reinterpret_cast<const f16x8*>(nxt + fa + tm * 32 * H3_ROWB + fo1);
         }
-        if constexpr (ISSUE) h3_glds16(gp[tm] + goff, dmad + tm * 1024);
     }
     if constexpr (NEXT) {
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) { bh[tn] = nbh[tn]; bl[tn] = nbl[tn]; }
+    }
+    // pin the issue order (the scheduler would otherwise cluster the DMA and the reads at the end
+    // of the stage, where both waves of a SIMD would stall on them together)
+    if constexpr (NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+        const bool dma = ISSUE && (tm >> 1) == PH;
+        if constexpr (FULLN) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            if (dma) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            if (dma) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            if (dma) __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+        }
+        if constexpr (NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     }
 }
 
@@ -130,7 +152,9 @@ __device__ __forceinline__ void h3_stage(f32x16 (&acc)[4][2], f16x8 (&ah)[4], f1
         __builtin_amdgcn_sched_barrier(0);             \
     } while (0)
 
-template <bool PAIRED, class Epi>
+// VARIANT != 0: timing-only diagnostics (wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads,
+// 3 neither, 4 no barrier
+template <bool PAIRED, class Epi, int VARIANT = 0>
 __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi epi) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int tid = threadIdx.x;
@@ -227,23 +251,26 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
     // ---- stages.  At the top of stage t the wave's own pieces of tile t+1 must have landed
     // (tile t+2 may stay in flight: vmcnt(4)); the barrier then makes tile t+1 readable for
     // everyone and proves that buffer (t+3)&3 — read last during stage t-2 — is free.
-#define H3_RUN(FULLN)                                                                                                  \
+#define H3_RUN(FULLN, PH)                                                                                              \
     {                                                                                                                  \
         int t = 0;                                                                                                     \
         for (; t + 3 < nkt; ++t) {                                                                                     \
             H3_WAIT_VM(4);                                                                                             \
-            H3_BARRIER();                                                                                              \
-            h3_stage<FULLN, true, true>(acc, ah, al, bh, bl, lds + ((t + 1) & 3) * H3_STAGE, fa, fb, fo0, fo1, gp,     \
-                                        (long)(t + 3) * H3_ROWB, lds + ((t + 3) & 3) * H3_STAGE + sdst);              \
+            if (VARIANT != 4) H3_BARRIER();                                                                            \
+            h3_stage<FULLN, VARIANT != 2 && VARIANT != 3, VARIANT != 1 && VARIANT != 3, PH>(                           \
+                acc, ah, al, bh, bl, lds + ((t + 1) & 3) * H3_STAGE, fa, fb, fo0, fo1, gp, (long)(t + 3) * H3_ROWB,    \
+                lds + ((t + 3) & 3) * H3_STAGE + sdst);                                                                \
         }                                                                                                              \
         for (; t + 1 < nkt; ++t) {                                                                                     \
             if (t + 2 < nkt) H3_WAIT_VM(4); else H3_WAIT_VM(0);                                                        \
             H3_BARRIER();                                                                                              \
-            h3_stage<FULLN, true, false>(acc, ah, al, bh, bl, lds + ((t + 1) & 3) * H3_STAGE, fa, fb, fo0, fo1, gp, 0, lds); \
+            h3_stage<FULLN, true, false, PH>(acc, ah, al, bh, bl, lds + ((t + 1) & 3) * H3_STAGE, fa, fb, fo0, fo1, gp, 0, lds); \
         }                                                                                                              \
-        h3_stage<FULLN, false, false>(acc, ah, al, bh, bl, lds, fa, fb, fo0, fo1, gp, 0, lds);                         \
+        h3_stage<FULLN, false, false, PH>(acc, ah, al, bh, bl, lds, fa, fb, fo0, fo1, gp, 0, lds);                     \
     }
-    if (full_n) H3_RUN(true) else H3_RUN(false)
+    // the two waves of a SIMD (w and w+4) issue their DMA in different halves of the stage
+    if (full_n) { if (stB) H3_RUN(true, 1) else H3_RUN(true, 0) }
+    else { if (stB) H3_RUN(false, 1) else H3_RUN(false, 0) }
 #undef H3_RUN
 
     // ---- epilogue: D col = l31, row = (r&3) + 8*(r>>2) + 4*h; scales of the LAST segment
@@ -318,11 +345,11 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
     }
 }
 
-template <bool PAIRED, class Epi>
+template <bool PAIRED, class Epi, int VARIANT = 0>
 inline hipError_t launch_gemm_h3(H3Args g, int batches, Epi epi, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_kernel<PAIRED, Epi>), hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_kernel<PAIRED, Epi, VARIANT>), hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS);
         attr_set = true;
     }
     g.tiles_m = (g.M + H3_BM - 1) / H3_BM;
@@ -344,7 +371,7 @@ inline hipError_t launch_gemm_h3(H3Args g, int batches, Epi epi, hipStream_t st)
         g.mp = 0; g.gw = 1;
         grid = dim3(8 * ((batches + 7) / 8) * g.tiles_m * g.tiles_n, 1, 1);
     }
-    hipLaunchKernelGGL((gemm_h3_kernel<PAIRED, Epi>), grid, dim3(H3_THREADS), H3_LDS, st, g, epi);
+    hipLaunchKernelGGL((gemm_h3_kernel<PAIRED, Epi, VARIANT>), grid, dim3(H3_THREADS), H3_LDS, st, g, epi);
     return hipGetLastError();
 }
 
@@ -373,8 +400,35 @@ __device__ __forceinline__ void h3_store_chunk(unsigned char* dst, const float* 
     *reinterpret_cast<f16x8*>(dst + 16) = lo;
 }
 
+// fused producers: a wave owns one row and lane l holds the 4 consecutive values of quad q
+// (k = 4q .. 4q+3, q = i*64 + l).  Lanes 2j and 2j+1 exchange their quads; the even lane stores
+// the hi half (16 B) of chunk j, the odd lane the lo half: consecutive lanes write consecutive
+// 16 B.  All 64 lanes must be active.
+__device__ __forceinline__ void h3_emit4(unsigned char* prow, int q, float4 v, float s) {
+    float4 p;
+    p.x = __shfl_xor(v.x, 1, 64); p.y = __shfl_xor(v.y, 1, 64); p.z = __shfl_xor(v.z, 1, 64); p.w = __shfl_xor(v.w, 1, 64);
+    const bool odd = q & 1;
+    const float4 a = odd ? p : v, b = odd ? v : p;
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    f16x8 out;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float xs = x[i] * s;
+        const _Float16 hi = (_Float16)xs;
+        out[i] = odd ? (_Float16)(xs - (float)hi) : hi;
+    }
+    *reinterpret_cast<f16x8*>(prow + (q >> 1) * 32 + (odd ? 16 : 0)) = out;
+}
+__device__ __forceinline__ float h3_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float h3_absmax4(float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+
 // generic producer: fp32 rows [R][K] (pitch ld floats, K % 8 == 0, K <= 2048) -> planes (pitch 4*Kp bytes,
 // Kp = K rounded up to 16, the tail zero-filled) + scale.  One wave per row.
+template <int UNUSED = 0>      // (a template so that the header can be included by several translation units)
 __global__ __launch_bounds__(256) void h3_split_rows_kernel(const float* __restrict__ x, long ld, unsigned char* __restrict__ planes,
                                                            float* __restrict__ scale, long R, int K, int Kp) {
     const int lane = threadIdx.x & 63;
@@ -412,7 +466,7 @@ __global__ __launch_bounds__(256) void h3_split_rows_kernel(const float* __restr
 
 inline hipError_t launch_h3_split_rows(const float* x, long ld, void* planes, float* scale, long R, int K, hipStream_t st) {
     const int Kp = (K + 15) / 16 * 16;
-    hipLaunchKernelGGL(h3_split_rows_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, x, ld, (unsigned char*)planes, scale, R, K, Kp);
+    hipLaunchKernelGGL(h3_split_rows_kernel<0>, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, x, ld, (unsigned char*)planes, scale, R, K, Kp);
     return hipGetLastError();
 }
 

@@ -174,11 +174,14 @@ __global__ void concat_vu_kernel(const float* __restrict__ v, const float* __res
 }
 
 // ------------------------------------------------------------------ model
+struct H3W { const unsigned char* p; const float* s; };
 struct LayerW {
     // FLASH
     const float *Whq, *ghq, *bhq, *cw_h, *cw_qk, *gamma, *beta, *Wo, *go, *bo, *cw_o;
     // FSMN
     const float *W1, *b1, *a1, *ln1g, *ln1b, *Wuv, *buv, *cw_uv, *Wl, *bl, *Wp, *w1T, *w2T, *ing, *inb, *pre, *ln2g, *ln2b, *W2, *b2;
+    // nn.Linear weights as split-f16 planes + row scales (gemm_h3.hpp), made once at create
+    H3W hWhq, hWo, hW1, hWuv, hWl, hWp, hW2;
 };
 
 }  // namespace
@@ -188,6 +191,8 @@ struct tdx_mf2 {
     int L;
     float* dev_weights;
     size_t n_weights;
+    unsigned char* dev_planes;      // split-f16 planes + scales of every nn.Linear weight
+    H3W hWenc, hWout;
     std::vector<LayerW> layers;
     const float *encT, *gn1g, *gn1b, *Wenc, *pe_scale, *inv_freq, *rot_freqs, *lnfg, *lnfb, *gn2g, *gn2b, *prelu, *Wout, *bout,
         *Wtg, *btg, *Wdec1, *decT;
@@ -204,7 +209,7 @@ struct Plan {
     int B, T, S, G, Sp, splits, kchunk, nblk_enc, nblk_gn, nchunk1, nchunk2;
     long M;
     // offsets in floats
-    size_t E, z, x, rs, hid, vu, qk4, Abuf, slab, kvu, o, t, hraw, h, hhat, uvpre, uv, f, p, c1, c2, gn, pe, rc, rsn, stat,
+    size_t E, z, x, rs, hid, vu, qk4, Abuf, slab, kvu, o, t, hraw, h, hp, hs, uvpre, uv, f, p, c1, c2, pe, rc, rsn, stat,
         part, tap0, tap1, mask, total;
 };
 
@@ -234,9 +239,11 @@ bool make_plan(const tdx_mf2* h, int B, int T, Plan& P) {
     P.slab = take((size_t)B * P.splits * QK * HID);
     P.kvu = take((size_t)B * QK * HID);
     P.o = take(M * 1024); P.t = take(M * C);
-    P.hraw = take(M * INNER); P.h = take(M * INNER); P.hhat = take(M * INNER);
+    P.hraw = take(M * INNER); P.h = take(M * INNER);
+    P.hp = take(M * 1024);      // split-f16 planes of the current GEMM's A operand (<= 1024 channels: 4 KB per row)
+    P.hs = take(M);             // and its row scales
     P.uvpre = take(M * C); P.uv = take(M * C); P.f = take(M * INNER); P.p = take(M * INNER);
-    P.c1 = take(M * INNER); P.c2 = take(M * INNER); P.gn = take(M * INNER);
+    P.c1 = take(M * INNER); P.c2 = take(M * INNER);
     P.pe = take((size_t)P.S * C); P.rc = take((size_t)P.S * 16); P.rsn = take((size_t)P.S * 16);
     P.stat = take((size_t)B * 2 + (size_t)2 * B * 256 * 2 + 64);
     size_t npart = (size_t)B * (P.nblk_enc > P.nblk_gn ? P.nblk_enc : P.nblk_gn) * 2;
@@ -333,6 +340,21 @@ int linear_gemm(const float* A, long lda, const float* W, int M, int N, int K, E
     GemmArgs g = make_args(M, N, make_seg(A, lda, W, K, K));
     if (launch_gemm_x6<false>(g, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
     return TDX_OK;
+}
+// nn.Linear on the split-f16 x3 core (gemm_h3.hpp): A already in planes
+template <class Epi>
+int linear_h3(const unsigned char* Ap, const float* As, int M, const H3W& W, int N, int K, Epi e, hipStream_t st) {
+    tdx::H3Args g{};
+    g.seg[0] = tdx::h3_seg(Ap, As, 4L * K, W.p, W.s, 4L * K, K);
+    g.nseg = 1; g.M = M; g.N = N;
+    if (tdx::launch_gemm_h3<false>(g, 1, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    return TDX_OK;
+}
+// ... A in fp32: split pass first (rows whose producer does not own whole rows)
+template <class Epi>
+int split_linear_h3(const float* A, long lda, unsigned char* hp, float* hs, int M, const H3W& W, int N, int K, Epi e, hipStream_t st) {
+    if (tdx::launch_h3_split_rows(A, lda, hp, hs, M, K, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    return linear_h3(hp, hs, M, W, N, K, e, st);
 }
 template <class Epi>
 int linear_gemm_f32(const float* A, long lda, const float* W, int M, int N, int K, Epi e, hipStream_t st) {
@@ -501,6 +523,7 @@ int tdx_mf2_create(const tdx_mf2_config* cfg, const void* blob, size_t blob_byte
     if (e != hipSuccess) { hipFree(dev); return tdx::fail_hip(e, __FILE__, __LINE__); }
 
     tdx_mf2* h = new tdx_mf2();
+    h->dev_planes = nullptr;
     h->device = device; h->L = L; h->dev_weights = dev; h->n_weights = host.size(); h->taps = 0; h->ev_used = 0;
     h->layers.resize(L);
     for (int l = 0; l < L; ++l) {
@@ -516,6 +539,32 @@ int tdx_mf2_create(const tdx_mf2_config* cfg, const void* blob, size_t blob_byte
     h->inv_freq = dev + invf; h->rot_freqs = dev + rotf; h->lnfg = dev + lnfg; h->lnfb = dev + lnfb; h->gn2g = dev + gn2g;
     h->gn2b = dev + gn2b; h->prelu = dev + prelu; h->Wout = dev + Wout; h->bout = dev + bout; h->Wtg = dev + Wtg; h->btg = dev + btg;
     h->Wdec1 = dev + Wdec1; h->decT = dev + decT;
+    // ---- split every nn.Linear weight [N][K] into f16 planes + row scales, once
+    {
+        struct Job { const float* w; int N, K; H3W* dst; };
+        std::vector<Job> jobs;
+        for (int l = 0; l < L; ++l) {
+            LayerW& w = h->layers[l];
+            jobs.push_back({w.Whq, HQ, C, &w.hWhq}); jobs.push_back({w.Wo, C, 1024, &w.hWo}); jobs.push_back({w.W1, INNER, C, &w.hW1});
+            jobs.push_back({w.Wuv, C, INNER, &w.hWuv}); jobs.push_back({w.Wl, INNER, INNER, &w.hWl});
+            jobs.push_back({w.Wp, INNER, INNER, &w.hWp}); jobs.push_back({w.W2, C, INNER, &w.hW2});
+        }
+        jobs.push_back({h->Wenc, C, C, &h->hWenc}); jobs.push_back({h->Wout, 2 * C, C, &h->hWout});
+        size_t bytes = 0;
+        for (const Job& j : jobs) bytes += (size_t)j.N * j.K * 4 + (size_t)al(j.N) * 4;
+        e = hipMalloc(&h->dev_planes, bytes);
+        if (e != hipSuccess) { hipFree(dev); delete h; return tdx::fail_hip(e, __FILE__, __LINE__); }
+        unsigned char* q = h->dev_planes;
+        for (const Job& j : jobs) {
+            float* sc = (float*)(q + (size_t)j.N * j.K * 4);
+            e = tdx::launch_h3_split_rows(j.w, j.K, q, sc, j.N, j.K, nullptr);
+            if (e != hipSuccess) { hipFree(h->dev_planes); hipFree(dev); delete h; return tdx::fail_hip(e, __FILE__, __LINE__); }
+            j.dst->p = q; j.dst->s = sc;
+            q += (size_t)j.N * j.K * 4 + (size_t)al(j.N) * 4;
+        }
+        e = hipDeviceSynchronize();
+        if (e != hipSuccess) { hipFree(h->dev_planes); hipFree(dev); delete h; return tdx::fail_hip(e, __FILE__, __LINE__); }
+    }
     *out = h;
     return TDX_OK;
 }
@@ -523,6 +572,7 @@ int tdx_mf2_create(const tdx_mf2_config* cfg, const void* blob, size_t blob_byte
 int tdx_mf2_destroy(tdx_mf2* h) {
     if (!h) return TDX_OK;
     if (h->dev_weights) hipFree(h->dev_weights);
+    if (h->dev_planes) hipFree(h->dev_planes);
     for (auto e : h->ev0) hipEventDestroy(e);
     for (auto e : h->ev1) hipEventDestroy(e);
     delete h;
@@ -594,9 +644,10 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
     const long M = P.M;
     float *E = ws + P.E, *z = ws + P.z, *x = ws + P.x, *rs = ws + P.rs, *hid = ws + P.hid, *vu = ws + P.vu, *qk4 = ws + P.qk4,
           *Abuf = ws + P.Abuf, *slab = ws + P.slab, *kvu = ws + P.kvu, *o = ws + P.o, *t = ws + P.t, *hraw = ws + P.hraw,
-          *hh = ws + P.h, *hhat = ws + P.hhat, *uvpre = ws + P.uvpre, *uv = ws + P.uv, *f = ws + P.f, *p = ws + P.p,
-          *c1 = ws + P.c1, *c2 = ws + P.c2, *gn = ws + P.gn, *pe = ws + P.pe, *rc = ws + P.rc, *rsn = ws + P.rsn, *stat = ws + P.stat;
+          *hh = ws + P.h, *hs = ws + P.hs, *uvpre = ws + P.uvpre, *uv = ws + P.uv, *f = ws + P.f, *p = ws + P.p,
+          *c1 = ws + P.c1, *c2 = ws + P.c2, *pe = ws + P.pe, *rc = ws + P.rc, *rsn = ws + P.rsn, *stat = ws + P.stat;
     double* part = (double*)(ws + P.part);
+    unsigned char* hp = (unsigned char*)(ws + P.hp);
     float* gnstat = stat;               // [B][2]
     float* stat1 = stat + al(2 * B);    // [B][256][2]
     float* stat2 = stat1 + (size_t)B * 512;
@@ -612,20 +663,18 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
     hipLaunchKernelGGL((gn_apply_kernel<0>), dim3((unsigned)((M * 128 + 255) / 256)), dim3(256), 0, st, E, gnstat, h->gn1g, h->gn1b,
                        (const float*)nullptr, (const float*)nullptr, t, M, S);
     LAUNCH_CHECK();
-    TRY(linear_gemm(t, C, h->Wenc, (int)M, C, C, EpiPosEnc{pe, h->pe_scale, z, x, S}, st));
+    TRY(split_linear_h3(t, C, hp, hs, (int)M, h->hWenc, C, C, EpiPosEnc{pe, h->pe_scale, z, x, S}, st));
 
     for (int l = 0; l < h->L; ++l) {
         const LayerW& w = h->layers[l];
         // ================= FLASH_ShareA_FFConvM  (mossformer_block.py:191-220)
-        hipLaunchKernelGGL((rowscale_kernel<C, true>), rows4(M), dim3(256), 0, st, x, rs, M, S);
+        // token shift + ScaleNorm statistics + split-f16 planes of the shifted row, one pass over x
+        hipLaunchKernelGGL((rowscale_split_kernel<C, true>), rows4(M), dim3(256), 0, st, x, rs, hp, hs, M, S);
         LAUNCH_CHECK();
         {
-            GemmArgs g = make_args((int)M, HQ, make_seg(x, C, w.Whq, C, C));
-            g.shift_k = C / 2; g.shift_S = S;
-            EpiHidden e{rs, w.ghq, w.bhq, hid, HQ};
             const bool prof = h->ev_used < h->ev0.size();
             if (prof) hipEventRecord(h->ev0[h->ev_used], st);
-            if (launch_gemm_x6<true>(g, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+            TRY(linear_h3(hp, hs, (int)M, w.hWhq, HQ, C, EpiHidden{rs, w.ghq, w.bhq, hid, HQ}, st));
             if (prof) { hipEventRecord(h->ev1[h->ev_used], st); h->ev_used++; }
         }
         {
@@ -638,9 +687,9 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
             TRY(launch_conv17<2>(q, B, st));
         }
         TRY(attention_core(qk4, vu, B, S, 1024, P.splits, P.kchunk, Abuf, slab, kvu, o, nullptr, nullptr, st));
-        hipLaunchKernelGGL((rowscale_kernel<1024, false>), rows4(M), dim3(256), 0, st, o, rs, M, S);
+        hipLaunchKernelGGL((rowscale_split_kernel<1024, false>), rows4(M), dim3(256), 0, st, o, rs, hp, hs, M, S);
         LAUNCH_CHECK();
-        TRY(linear_gemm(o, 1024, w.Wo, (int)M, C, 1024, EpiHidden{rs, w.go, w.bo, t, C}, st));
+        TRY(linear_h3(hp, hs, (int)M, w.hWo, C, 1024, EpiHidden{rs, w.go, w.bo, t, C}, st));
         {
             Conv17Args a{};
             a.in = t; a.ld_in = C; a.col0 = 0; a.wT = w.cw_o; a.C = C; a.out = x; a.ld_out = C; a.S = S; a.Sp = Sp;
@@ -648,22 +697,23 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
         }
         if (h->taps && l == 0) hipMemcpyAsync(ws + P.tap0, x, M * C * sizeof(float), hipMemcpyDeviceToDevice, st);
         // ================= GatedFSMNBlockDilated  (mossformer_block.py:419-425)
-        TRY(linear_gemm(x, C, w.W1, (int)M, INNER, C, EpiBiasPrelu{w.b1, w.a1, hraw, INNER}, st));
-        hipLaunchKernelGGL((layernorm_kernel<INNER, true>), rows4(M), dim3(256), 0, st, hraw, w.ln1g, w.ln1b, hh, hhat, M, 1e-5f);
+        TRY(split_linear_h3(x, C, hp, hs, (int)M, w.hW1, INNER, C, EpiBiasPrelu{w.b1, w.a1, hraw, INNER}, st));
+        hipLaunchKernelGGL((layernorm_kernel<INNER, true>), rows4(M), dim3(256), 0, st, hraw, w.ln1g, w.ln1b, hh, (float*)nullptr, M, 1e-5f,
+                           hp, hs);
         LAUNCH_CHECK();
-        TRY(linear_gemm(hhat, INNER, w.Wuv, (int)M, C, INNER, EpiBiasSilu{w.buv, uvpre, C}, st));
+        TRY(linear_h3(hp, hs, (int)M, w.hWuv, C, INNER, EpiBiasSilu{w.buv, uvpre, C}, st));
         {
             Conv17Args a{};
             a.in = uvpre; a.ld_in = C; a.col0 = 0; a.wT = w.cw_uv; a.C = C; a.out = uv; a.ld_out = C; a.S = S; a.Sp = Sp;
             TRY(launch_conv17<0>(a, B, st));
         }
-        TRY(linear_gemm(uv, C, w.Wl, (int)M, INNER, INNER, EpiBiasRelu{w.bl, f, INNER}, st));
-        TRY(linear_gemm(f, INNER, w.Wp, (int)M, INNER, INNER, EpiBias{nullptr, p, INNER}, st));
+        TRY(split_linear_h3(uv, C, hp, hs, (int)M, w.hWl, INNER, INNER, EpiBiasRelu{w.bl, f, INNER}, st));
+        TRY(split_linear_h3(f, INNER, hp, hs, (int)M, w.hWp, INNER, INNER, EpiBias{nullptr, p, INNER}, st));
         TRY(ddn_core(p, B, S, w.w1T, w.w2T, w.ing, w.inb, w.pre, c1, c2, stat1, stat2, part, st));
         hipLaunchKernelGGL(fsmn_tail_kernel, rows4(M), dim3(256), 0, st, c2, stat2, w.ing + INNER, w.inb + INNER, w.pre + INNER, uv, hh,
-                           w.ln2g, w.ln2b, gn, M, S);
+                           w.ln2g, w.ln2b, hp, hs, M, S);
         LAUNCH_CHECK();
-        TRY(linear_gemm(gn, INNER, w.W2, (int)M, C, INNER, EpiBiasResidual{w.b2, x, C}, st));
+        TRY(linear_h3(hp, hs, (int)M, w.hW2, C, INNER, EpiBiasResidual{w.b2, x, C}, st));
         if (h->taps && l == 0) hipMemcpyAsync(ws + P.tap1, x, M * C * sizeof(float), hipMemcpyDeviceToDevice, st);
     }
 
@@ -679,7 +729,7 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
                        h->prelu, r, M, S);
     LAUNCH_CHECK();
     float* r2 = o;       // [M,1024]
-    TRY(linear_gemm(r, C, h->Wout, (int)M, 2 * C, C, EpiBias{h->bout, r2, 2 * C}, st));
+    TRY(split_linear_h3(r, C, hp, hs, (int)M, h->hWout, 2 * C, C, EpiBias{h->bout, r2, 2 * C}, st));
     float* gate = vu;    // [2][M][512]
     {
         GemmArgs g = make_args((int)M, C, make_seg(r2, 2 * C, h->Wtg, C, C, C, 0));
@@ -834,6 +884,19 @@ int tdx_linear_variant(const float* a, const float* w, int M, int N, int K, floa
 int tdx_h3_split_rows(const float* x, long ld, void* planes, float* scale, long R, int K, void* stream) {
     if (K % 8 || K > 2048) return tdx::fail(TDX_E_INVALID, "tdx_h3_split_rows: need K%8==0, K<=2048");
     hipError_t r = tdx::launch_h3_split_rows(x, ld, planes, scale, R, K, (hipStream_t)stream);
+    return r == hipSuccess ? TDX_OK : tdx::fail_hip(r, __FILE__, __LINE__);
+}
+int tdx_h3_gemm_variant(const void* pa, const float* sa, const void* pb, const float* sb, const float* bias, float* c, int M, int N, int K, int variant, void* stream) {
+    tdx::H3Args g{};
+    g.seg[0] = tdx::h3_seg(pa, sa, 4L * K, pb, sb, 4L * K, K);
+    g.nseg = 1; g.M = M; g.N = N;
+    EpiBias e{bias, c, N};
+    hipError_t r;
+    if (variant == 1) r = tdx::launch_gemm_h3<false, EpiBias, 1>(g, 1, e, (hipStream_t)stream);
+    else if (variant == 2) r = tdx::launch_gemm_h3<false, EpiBias, 2>(g, 1, e, (hipStream_t)stream);
+    else if (variant == 3) r = tdx::launch_gemm_h3<false, EpiBias, 3>(g, 1, e, (hipStream_t)stream);
+    else if (variant == 4) r = tdx::launch_gemm_h3<false, EpiBias, 4>(g, 1, e, (hipStream_t)stream);
+    else r = tdx::launch_gemm_h3<false, EpiBias, 0>(g, 1, e, (hipStream_t)stream);
     return r == hipSuccess ? TDX_OK : tdx::fail_hip(r, __FILE__, __LINE__);
 }
 int tdx_h3_gemm(const void* pa, const float* sa, const void* pb, const float* sb, const float* bias, float* c, int M, int N, int K, void* stream) {

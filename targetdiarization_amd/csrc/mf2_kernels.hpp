@@ -156,6 +156,39 @@ __global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__
     }
 }
 
+// same, and the (shifted) row is also written as split-f16 planes + exponent scale for the x3 GEMM
+// (gemm_h3.hpp): the GEMM then reads 4C bytes per row of planes instead of the fp32 row.
+template <int C, bool SHIFT>
+__global__ __launch_bounds__(256) void rowscale_split_kernel(const float* __restrict__ x, float* __restrict__ rs,
+                                                              unsigned char* __restrict__ hp, float* __restrict__ hs, long M, int S) {
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int lane = threadIdx.x & 63;
+    float acc = 0.f, mu = 0.f;
+    float4 v[C / 256];
+#pragma unroll
+    for (int i = 0; i < C / 256; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        long row = m;
+        bool ok = true;
+        if (SHIFT && c < C / 2) { ok = (m % S) != 0; row = m - 1; }
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v[i] = *reinterpret_cast<const float4*>(x + row * C + c);
+        acc += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        mu = fmaxf(mu, h3_absmax4(v[i]));
+    }
+    acc = wave_sum(acc);
+    float inv;
+    const float sc = h3_row_scale(h3_wave_max(mu), inv);
+#pragma unroll
+    for (int i = 0; i < C / 256; ++i) h3_emit4(hp + m * (4L * C), i * 64 + lane, v[i], sc);
+    if (lane == 0) {
+        const float nrm = sqrtf(acc) * (C == 512 ? 0.044194173824159216f : 0.03125f);
+        rs[m] = 1.0f / fmaxf(nrm, 1e-5f);
+        hs[m] = inv;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // DilatedDenseNet (fsmn.py:76-111), token-major, one thread per channel, 256 threads.
 //  conv1: c1 = dwconv_{k=39,dil=1,pad=19}(p)                         (+ IN statistics)
@@ -297,7 +330,8 @@ __global__ __launch_bounds__(256) void fsmn_tail_kernel(const float* __restrict_
                                                          const float* __restrict__ in_g, const float* __restrict__ in_b,
                                                          const float* __restrict__ prelu, const float* __restrict__ uv,
                                                          const float* __restrict__ hh, const float* __restrict__ ln_g,
-                                                         const float* __restrict__ ln_b, float* __restrict__ gn, long M, int S) {
+                                                         const float* __restrict__ ln_b, unsigned char* __restrict__ hp,
+                                                         float* __restrict__ hs, long M, int S) {
     const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
     const int lane = threadIdx.x & 63, c = lane * 4;
@@ -332,7 +366,11 @@ __global__ __launch_bounds__(256) void fsmn_tail_kernel(const float* __restrict_
     float4 r;
     r.x = g[0] * rstd * lg.x + lb.x; r.y = g[1] * rstd * lg.y + lb.y;
     r.z = g[2] * rstd * lg.z + lb.z; r.w = g[3] * rstd * lg.w + lb.w;
-    *reinterpret_cast<float4*>(gn + m * 256 + c) = r;
+    // the only consumer is the conv2 1x1 GEMM: written as split-f16 planes (gemm_h3.hpp)
+    float inv;
+    const float sc = h3_row_scale(h3_wave_max(h3_absmax4(r)), inv);
+    h3_emit4(hp + m * 1024L, lane, r, sc);
+    if (lane == 0) hs[m] = inv;
 }
 
 // Kvu[b][d][c] = (sum_sp slab[b][sp][d][c]) / S      (mossformer_block.py:286,289)

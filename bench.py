@@ -33,11 +33,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
-X6_PASSES = 6                    # bf16 MFMA passes per fp32-accurate product (csrc/gemm_x6.hpp)
-# Roofline of the dominant kernel: it computes fp32-accurate products as 6 bf16 MFMA passes, so
-# its ceiling in ALGORITHMIC FLOP/s is the dense bf16 MFMA peak / 6 = 416.7 TFLOP/s.
-PEAK_X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / X6_PASSES
+PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak
+H3_PASSES = 3                    # f16 MFMA passes per fp32-accurate product (csrc/gemm_h3.hpp)
+# Roofline of the dominant kernel: it computes fp32-accurate products as 3 f16 MFMA passes over
+# exponent-aligned split operands, so its ceiling in ALGORITHMIC FLOP/s is the dense f16 MFMA
+# peak / 3 = 833.3 TFLOP/s.
+PEAK_H3_TFLOPS = PEAK_F16_MFMA_TFLOPS / H3_PASSES
 
 
 def synth_mixtures(batch: int, n: int, seed: int) -> np.ndarray:
@@ -238,13 +239,13 @@ def main():
                                    f"{args.seconds:g} s 16 kHz 2-speaker mixtures per GPU, 24 blocks, recipe weights",
                        "per_gpu_batch": B, "samples_per_window": T, "frames_per_window": S,
                        "parallelism": f"{world} independent replicas (windows sharded, no collective)"},
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_X6_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (ach / PEAK_X6_TFLOPS) if ach else None, "traffic": traffic,
-                         "kernel": "gemm_x6_kernel<to_hidden+to_qk: token-shift A-load, split-bf16 x6 MFMA, ScaleNorm+SiLU epilogue>",
-                         "peak_note": "algorithmic fp32-accurate FLOP/s ceiling of the kernel = dense bf16 MFMA peak 2500 / 6 passes; "
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_H3_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (ach / PEAK_H3_TFLOPS) if ach else None, "traffic": traffic,
+                         "kernel": "gemm_h3_kernel<to_hidden+to_qk: split-f16 x3 MFMA over pre-split planes, ScaleNorm+SiLU epilogue>",
+                         "peak_note": "algorithmic fp32-accurate FLOP/s ceiling of the kernel = dense f16 MFMA peak 2500 / 3 passes; "
                                       "vs the fp32-input MFMA peak (157.3) the same number is frac_vs_f32_mfma_peak",
                          "frac_vs_f32_mfma_peak": (ach / PEAK_F32_MFMA_TFLOPS) if ach else None,
-                         "mfma_pipe_executed_tflops": (ach * X6_PASSES) if ach else None,
+                         "mfma_pipe_executed_tflops": (ach * H3_PASSES) if ach else None,
                          "launches_timed": gemm_launches, "ms_per_launch": gemm_ms / max(gemm_launches, 1),
                          "algorithmic_flops_per_launch": gemm_flops,
                          "whole_path_tflops_per_gpu": flops_step * args.steps / dt / 1e12,

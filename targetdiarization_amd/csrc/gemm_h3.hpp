@@ -25,19 +25,27 @@
 //
 // Tiling: 256 x 256 x 16 block tile, 8 waves as 2(M) x 4(N), wave tile 128 x 64 = 4 x 2 MFMA
 // tiles (128 accumulator VGPRs), 1 block per CU.  No VALU work in the main loop: operands go
-// global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 16 rows x 64 B per wave
-// instruction, 4 per wave per k-tile) into a ring of FOUR 32 KB stages; the DMA of tile t+3 is
-// issued during the MFMAs of tile t and waited for with a COUNTED vmcnt (never 0 in steady
-// state) before the raw s_barrier that opens stage t+2.  Fragments of tile t+1 are read from
-// LDS during the MFMAs of tile t (A fragments into the registers the finished row of MFMA
-// tiles just released, B fragments into a second register set), so a stage is
-//     [vmcnt(4); s_barrier]  4 x { 6 MFMA ; 2-3 ds_read_b128 ; 1 LDS-DMA }
+// global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction, 4 per wave per
+// k-tile) into a ring of FOUR 32 KB stages; the DMA of tile t+3 is issued during the MFMAs of
+// tile t and waited for with a COUNTED vmcnt (never 0 in steady state) before the raw s_barrier
+// that opens stage t+2.  Fragments of tile t+1 are read from LDS during the MFMAs of tile t (A
+// fragments into the registers the finished row of MFMA tiles just released, B fragments into
+// a second register set), so a stage is
+//     [vmcnt(4); s_barrier]  4 x { 6 MFMA ; fragment reads ; 1 LDS-DMA }
 // with nothing exposed but the barrier itself.
-// LDS image: row pitch 64 B (16 k x 2 planes x 2 B), the 16-B slot q of row r is stored at
-// slot q ^ ((r>>2)&3); the swizzle is applied on the per-lane SOURCE address (the LDS-DMA
-// destination is lane-linear) and on the fragment read.  With it the four 16-lane groups of a
-// ds_read_b128 (rows {0-3,12-15,20-27}, {4-11,16-19,28-31} of a 32-row fragment) touch 16
-// distinct 16-B bank slots: conflict-free.
+//
+// Two operand formats, chosen per operand by A_TR / B_TR:
+//  * row-major planes (above): one operand row = one matrix row, k contiguous.  LDS image: row
+//    pitch 64 B (16 k x 2 planes x 2 B), the 16-B slot q of row r stored at slot q ^ ((r>>2)&3),
+//    read with ds_read_b128 (conflict-free over its four 16-lane groups).
+//  * K-major planes ("TR"): the matrix is stored [k][n/128][2 planes][128] f16 — k is the
+//    slow index, as activations indexed by token are — with ONE scale for the whole matrix
+//    (a static bound, see mf2.hip).  LDS image per k row: 1 KiB = [blk 0: hi 256 B | lo 256 B]
+//    [blk 1: ...], the 64-B windows of a 256-B plane row permuted by window ^ (k&3); fragments
+//    are gathered with ds_read_b64_tr_b16 (4 k x 16 n per 16-lane group, two per fragment),
+//    conflict-free per 32-lane half.
+// In both cases the swizzle is applied on the per-lane SOURCE address of the DMA (its LDS
+// destination is lane-linear) and on the fragment read.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -56,14 +64,15 @@ constexpr int H3_NBUF = 4;
 constexpr int H3_LDS = H3_NBUF * H3_STAGE;    // 128 KB
 
 struct H3Seg {
-    const unsigned char* A;      // planes of the A rows  (row pitch lda bytes)
-    const unsigned char* B;      // planes of the B rows ([N][K]: one row per output column)
-    const float* sa;             // [M] row scales of A
-    const float* sb;             // [N] row scales of B
-    long lda, ldb;               // bytes
+    const unsigned char* A;      // planes of the A operand
+    const unsigned char* B;      // planes of the B operand
+    const float* sa;             // row scales of A   (element m * sa_mul: sa_mul = 0 -> one scale for all rows)
+    const float* sb;             // column scales of B (element n * sb_mul)
+    long lda, ldb;               // bytes: row-major planes: pitch of a matrix row; K-major: pitch of a k row
     // batch z -> z1 = z / zdiv, z2 = z % zdiv ; pointer += z1*stride + z2*stride2
     long strideA, strideB, strideA2, strideB2;          // bytes
     long strideSA, strideSB, strideSA2, strideSB2;      // floats
+    int sa_mul, sb_mul;
     int K;                       // multiple of 16
     int zdiv;
 };
@@ -80,6 +89,7 @@ struct H3Args {
 inline H3Seg h3_seg(const void* A, const float* sa, long lda, const void* B, const float* sb, long ldb, int K) {
     H3Seg s{};
     s.A = (const unsigned char*)A; s.B = (const unsigned char*)B; s.sa = sa; s.sb = sb; s.lda = lda; s.ldb = ldb; s.K = K; s.zdiv = 1;
+    s.sa_mul = 1; s.sb_mul = 1;
     return s;
 }
 
@@ -87,19 +97,55 @@ __device__ __forceinline__ void h3_glds16(const unsigned char* g, unsigned char*
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+typedef __fp16 h3_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// fragment (32 operand rows x 16 k, one plane) for lane (row l31, k = 8h .. 8h+7)
+template <bool TR>
+__device__ __forceinline__ f16x8 h3_frag(const unsigned char* p) {
+    if constexpr (!TR) {
+        return *reinterpret_cast<const f16x8*>(p);
+    } else {
+        // p = address of (k row 8h+q, 4 columns) for this lane; the second gather is 4 k rows (4 KiB) further
+        const h3_fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h3_fp16x4*)p);
+        const h3_fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h3_fp16x4*)(p + 4096));
+        f16x8 r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { r[i] = (_Float16)lo[i]; r[4 + i] = (_Float16)hi[i]; }
+        return r;
+    }
+}
+
+// Per-lane fragment addressing inside a stage buffer.
+//   row-major planes: A tile tm, plane pl at  a0 + tm*2048 + apl[pl];  B tile tn at  b0 + tn*8192 + bpl[pl]
+//   K-major planes  : A tile tm, plane pl at  at[tm] + pl*256;          B tile tn at  b0 + tn*512 + pl*256
+struct H3Frag { int a0, apl[2], at[4], b0, bpl[2]; };
+
+template <bool A_TR>
+__device__ __forceinline__ const unsigned char* h3_addr_a(const unsigned char* st, const H3Frag& f, int tm, int pl) {
+    if constexpr (A_TR) return st + f.at[tm] + pl * 256;
+    else return st + f.a0 + tm * 2048 + f.apl[pl];
+}
+template <bool B_TR>
+__device__ __forceinline__ const unsigned char* h3_addr_b(const unsigned char* st, const H3Frag& f, int tn, int pl) {
+    if constexpr (B_TR) return st + f.b0 + tn * 512 + pl * 256;
+    else return st + f.b0 + tn * 8192 + f.bpl[pl];
+}
+
 // one pipeline stage: MFMAs of the tile whose fragments are in (ah, al, bh, bl); with NEXT the
 // fragments of the following tile are read from stage buffer `nxt`; with ISSUE the wave's four
 // LDS-DMA pieces of the tile three ahead are issued (src = gp[j] + goff, dst = dmad + j KiB).
-template <bool FULLN, bool NEXT, bool ISSUE, int PH>
+// PH: the half of the stage in which this wave issues its DMA (the two waves of a SIMD differ).
+template <bool A_TR, bool B_TR, bool FULLN, bool NEXT, bool ISSUE, int PH>
 __device__ __forceinline__ void h3_stage(f32x16 (&acc)[4][2], f16x8 (&ah)[4], f16x8 (&al)[4], f16x8 (&bh)[2], f16x8 (&bl)[2],
-                                         const unsigned char* nxt, int fa, int fb, int fo0, int fo1,
+                                         const unsigned char* nxt, const H3Frag& f,
                                          const unsigned char* const (&gp)[4], long goff, unsigned char* dmad) {
     f16x8 nbh[2], nbl[2];
     if constexpr (NEXT) {
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            nbh[tn] = *reinterpret_cast<const f16x8*>(nxt + fb + tn * 128 * H3_ROWB + fo0);
-            nbl[tn] = *reinterpret_cast<const f16x8*>(nxt + fb + tn * 128 * H3_ROWB + fo1);
+        for (int tn = 0; tn < (FULLN ? 2 : 1); ++tn) {
+            nbh[tn] = h3_frag<B_TR>(h3_addr_b<B_TR>(nxt, f, tn, 0));
+            nbl[tn] = h3_frag<B_TR>(h3_addr_b<B_TR>(nxt, f, tn, 1));
         }
     }
 #pragma unroll
@@ -117,17 +163,18 @@ __device__ __forceinline__ void h3_stage(f32x16 (&acc)[4][2], f16x8 (&ah)[4], f1
             if ((tm >> 1) == PH) h3_glds16(gp[(tm & 1) * 2 + 1] + goff, dmad + ((tm & 1) * 2 + 1) * 1024);
         }
         if constexpr (NEXT) {
-            ah[tm] = *reinterpret_cast<const f16x8*>(nxt + fa + tm * 32 * H3_ROWB + fo0);
-            al[tm] = *reinterpret_cast<const f16x8*>(nxt + fa + tm * 32 * H3_ROWB + fo1);
+            ah[tm] = h3_frag<A_TR>(h3_addr_a<A_TR>(nxt, f, tm, 0));
+            al[tm] = h3_frag<A_TR>(h3_addr_a<A_TR>(nxt, f, tm, 1));
         }
     }
     if constexpr (NEXT) {
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) { bh[tn] = nbh[tn]; bl[tn] = nbl[tn]; }
+        for (int tn = 0; tn < (FULLN ? 2 : 1); ++tn) { bh[tn] = nbh[tn]; bl[tn] = nbl[tn]; }
     }
     // pin the issue order (the scheduler would otherwise cluster the DMA and the reads at the end
     // of the stage, where both waves of a SIMD would stall on them together)
-    if constexpr (NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    constexpr int RA = A_TR ? 4 : 2, RB = (B_TR ? 4 : 2) * (FULLN ? 2 : 1);
+    if constexpr (NEXT) __builtin_amdgcn_sched_group_barrier(0x100, RB, 0);
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm) {
         const bool dma = ISSUE && (tm >> 1) == PH;
@@ -140,7 +187,7 @@ __device__ __forceinline__ void h3_stage(f32x16 (&acc)[4][2], f16x8 (&ah)[4], f1
             __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
             if (dma) __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
         }
-        if constexpr (NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        if constexpr (NEXT) __builtin_amdgcn_sched_group_barrier(0x100, RA, 0);
     }
 }
 
@@ -152,9 +199,10 @@ __device__ __forceinline__ void h3_stage(f32x16 (&acc)[4][2], f16x8 (&ah)[4], f1
         __builtin_amdgcn_sched_barrier(0);             \
     } while (0)
 
-// VARIANT != 0: timing-only diagnostics (wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads,
-// 3 neither, 4 no barrier
-template <bool PAIRED, class Epi, int VARIANT = 0>
+// A_TR / B_TR: operand in K-major planes.  TWOSEG: two K segments (same operand formats, their own
+// pointers and scales).  VARIANT != 0: timing-only diagnostics (wrong results): 1 no LDS-DMA in
+// the loop, 2 no fragment reads, 3 neither, 4 no barrier.
+template <bool A_TR, bool B_TR, bool PAIRED, bool TWOSEG, class Epi, int VARIANT = 0>
 __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi epi) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int tid = threadIdx.x;
@@ -193,93 +241,154 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // staging role: waves 0-3 fetch the A tile, waves 4-7 the B tile; piece j of a wave = LDS rows
-    // (wave&3)*64 + 16j .. +15, lane -> row +(lane>>2), LDS slot lane&3, source slot (lane&3)^((row>>2)&3)
+    // staging role: waves 0-3 fetch the A tile, waves 4-7 the B tile, four 1-KiB pieces each per stage.
+    //   row-major planes: piece j = LDS rows (wave&3)*64 + 16j .. +15, lane -> row +(lane>>2), slot lane&3,
+    //                     source slot (lane&3) ^ ((row>>2)&3)
+    //   K-major planes  : piece j = k row (wave&3)*4 + j, lane -> blk lane>>5, plane (lane>>4)&1, slot lane&15,
+    //                     source slot (lane&15) ^ (j<<2)         ((k&3) = j)
     const bool stB = wave >= 4;
-    const int srow = (wave & 3) * 64 + (lane >> 2);
-    const int sdst = (stB ? H3_OPER : 0) + (wave & 3) * 64 * H3_ROWB;
-    // fragment reads: per-lane slot offsets of the hi / lo plane (k = 8h .. 8h+7 of the 16-k tile)
-    const int fl = (l31 >> 2) & 3;
-    const int fo0 = ((2 * h) ^ fl) << 4, fo1 = ((2 * h + 1) ^ fl) << 4;
-    const int fa = (wm * 128 + l31) * H3_ROWB;              // + tm * 32 rows
-    const int fb = H3_OPER + (wn * 32 + l31) * H3_ROWB;     // + tn * 128 rows
+    const int sdst = (stB ? H3_OPER : 0) + (wave & 3) * 4096;
+    H3Frag f;
+    {
+        const int fl = (l31 >> 2) & 3;                       // row-major: slot swizzle of the lane's row
+        const int q = (lane >> 2) & 3, p4 = lane & 3, nb = (lane >> 4) & 1;     // K-major gather roles
+        f.a0 = (wm * 128 + l31) * H3_ROWB;
+        f.apl[0] = ((2 * h) ^ fl) << 4; f.apl[1] = ((2 * h + 1) ^ fl) << 4;
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) f.at[tm] = (8 * h + q) * 1024 + wm * 512 + (((tm ^ q) << 6) + nb * 32 + p4 * 8);
+        if constexpr (B_TR) f.b0 = H3_OPER + (8 * h + q) * 1024 + (((wn ^ q) << 6) + nb * 32 + p4 * 8);
+        else f.b0 = H3_OPER + (wn * 32 + l31) * H3_ROWB;
+        f.bpl[0] = f.apl[0]; f.bpl[1] = f.apl[1];
+    }
     const bool full_n = PAIRED || (n0 + 128 < g.N);
 
-    const int z1 = z / g.seg[0].zdiv, z2 = z - z1 * g.seg[0].zdiv;
-    const int nkt = g.seg[0].K / H3_BK;
-    const unsigned char* gp[4];
-    if (!stB) {
-        const unsigned char* Ag = g.seg[0].A + (long)z1 * g.seg[0].strideA + (long)z2 * g.seg[0].strideA2;
+    for (int s = 0; s < (TWOSEG ? 2 : 1); ++s) {
+        const H3Seg& sg = g.seg[TWOSEG ? s : 0];
+        const int z1 = z / sg.zdiv, z2 = z - z1 * sg.zdiv;
+        const int nkt = sg.K / H3_BK;
+        const unsigned char* gp[4];
+        long gstep;
+        if (!stB) {
+            const unsigned char* Ag = sg.A + (long)z1 * sg.strideA + (long)z2 * sg.strideA2;
+            if constexpr (!A_TR) {
+                gstep = H3_ROWB;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = srow + 16 * j;
-            const int q = (lane & 3) ^ ((r >> 2) & 3);
-            gp[j] = Ag + (long)min(m0 + r, g.M - 1) * g.seg[0].lda + q * 16;
-        }
-    } else {
-        const unsigned char* Bg = g.seg[0].B + (long)z1 * g.seg[0].strideB + (long)z2 * g.seg[0].strideB2;
+                for (int j = 0; j < 4; ++j) {
+                    const int r = (wave & 3) * 64 + (lane >> 2) + 16 * j;
+                    gp[j] = Ag + (long)min(m0 + r, g.M - 1) * sg.lda + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
+                }
+            } else {
+                gstep = 16 * sg.lda;
+                const int blk = min(m0 / 128 + (lane >> 5), (g.M - 1) / 128);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = srow + 16 * j;
-            const int q = (lane & 3) ^ ((r >> 2) & 3);
-            const int n = PAIRED ? (r < 128 ? n0 + r : g.pair_off + n0 + r - 128) : min(n0 + r, g.N - 1);
-            gp[j] = Bg + (long)n * g.seg[0].ldb + q * 16;
+                for (int j = 0; j < 4; ++j)
+                    gp[j] = Ag + (long)((wave & 3) * 4 + j) * sg.lda + blk * 512 + ((lane >> 4) & 1) * 256 + (((lane & 15) ^ (j << 2)) << 4);
+            }
+        } else {
+            const unsigned char* Bg = sg.B + (long)z1 * sg.strideB + (long)z2 * sg.strideB2;
+            if constexpr (!B_TR) {
+                gstep = H3_ROWB;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = (wave & 3) * 64 + (lane >> 2) + 16 * j;
+                    const int n = PAIRED ? (r < 128 ? n0 + r : g.pair_off + n0 + r - 128) : min(n0 + r, g.N - 1);
+                    gp[j] = Bg + (long)n * sg.ldb + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
+                }
+            } else {
+                gstep = 16 * sg.ldb;
+                const int ncol = PAIRED ? ((lane >> 5) ? g.pair_off + n0 : n0) : min(n0 + 128 * (lane >> 5), g.N - 128);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    gp[j] = Bg + (long)((wave & 3) * 4 + j) * sg.ldb + (ncol / 128) * 512 + ((lane >> 4) & 1) * 256 + (((lane & 15) ^ (j << 2)) << 4);
+            }
         }
-    }
+        if (TWOSEG && s > 0) {
+            // scale domain change: acc holds sum / (sa0[m]*sb0[n]); continue in units of sa1[m]*sb1[n].
+            // Powers of two, so the rescale is exact.  (memory clobbers keep the loads from being
+            // hoisted into one 64-register burst)
+            const H3Seg& s0 = g.seg[0];
+            const int y1 = z / s0.zdiv, y2 = z - y1 * s0.zdiv;
+            const float* sa0 = s0.sa + (long)y1 * s0.strideSA + (long)y2 * s0.strideSA2;
+            const float* sb0 = s0.sb + (long)y1 * s0.strideSB + (long)y2 * s0.strideSB2;
+            const float* sa1 = sg.sa + (long)z1 * sg.strideSA + (long)z2 * sg.strideSA2;
+            const float* sb1 = sg.sb + (long)z1 * sg.strideSB + (long)z2 * sg.strideSB2;
+            float cf[2];
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const int c = PAIRED ? (tn == 0 ? n0 + wn * 32 + l31 : g.pair_off + n0 + wn * 32 + l31) : min(n0 + tn * 128 + wn * 32 + l31, g.N - 1);
+                cf[tn] = sb0[(long)c * s0.sb_mul] / sb1[(long)c * sg.sb_mul];
+            }
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = min(m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, g.M - 1);
+                    const float rf = sa0[(long)m * s0.sa_mul] / sa1[(long)m * sg.sa_mul];
+                    acc[tm][0][r] *= rf * cf[0];
+                    acc[tm][1][r] *= rf * cf[1];
+                }
+                asm volatile("" ::: "memory");
+            }
+            __syncthreads();      // every wave is done with the stage buffers the next DMA overwrites
+        }
 
-    // ---- prologue: tiles 0..2 in flight, fragments of tile 0 in registers
+        // ---- prologue: tiles 0..2 in flight, fragments of tile 0 in registers
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
-        if (p < nkt) {
+        for (int p = 0; p < 3; ++p)
+            if (p < nkt) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) h3_glds16(gp[j] + p * H3_ROWB, lds + p * H3_STAGE + sdst + j * 1024);
+                for (int j = 0; j < 4; ++j) h3_glds16(gp[j] + p * gstep, lds + p * H3_STAGE + sdst + j * 1024);
+            }
+        if (nkt >= 3) H3_WAIT_VM(8); else if (nkt == 2) H3_WAIT_VM(4); else H3_WAIT_VM(0);
+        H3_BARRIER();
+        f16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            bh[tn] = h3_frag<B_TR>(h3_addr_b<B_TR>(lds, f, tn, 0));
+            bl[tn] = h3_frag<B_TR>(h3_addr_b<B_TR>(lds, f, tn, 1));
         }
-    if (nkt >= 3) H3_WAIT_VM(8); else if (nkt == 2) H3_WAIT_VM(4); else H3_WAIT_VM(0);
-    H3_BARRIER();
-    f16x8 ah[4], al[4], bh[2], bl[2];
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-        bh[tn] = *reinterpret_cast<const f16x8*>(lds + fb + tn * 128 * H3_ROWB + fo0);
-        bl[tn] = *reinterpret_cast<const f16x8*>(lds + fb + tn * 128 * H3_ROWB + fo1);
-    }
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
-        ah[tm] = *reinterpret_cast<const f16x8*>(lds + fa + tm * 32 * H3_ROWB + fo0);
-        al[tm] = *reinterpret_cast<const f16x8*>(lds + fa + tm * 32 * H3_ROWB + fo1);
-    }
+        for (int tm = 0; tm < 4; ++tm) {
+            ah[tm] = h3_frag<A_TR>(h3_addr_a<A_TR>(lds, f, tm, 0));
+            al[tm] = h3_frag<A_TR>(h3_addr_a<A_TR>(lds, f, tm, 1));
+        }
 
-    // ---- stages.  At the top of stage t the wave's own pieces of tile t+1 must have landed
-    // (tile t+2 may stay in flight: vmcnt(4)); the barrier then makes tile t+1 readable for
-    // everyone and proves that buffer (t+3)&3 — read last during stage t-2 — is free.
+        // ---- stages.  At the top of stage t the wave's own pieces of tile t+1 must have landed
+        // (tile t+2 may stay in flight: vmcnt(4)); the barrier then makes tile t+1 readable for
+        // everyone and proves that buffer (t+3)&3 — read last during stage t-2 — is free.
 #define H3_RUN(FULLN, PH)                                                                                              \
-    {                                                                                                                  \
-        int t = 0;                                                                                                     \
-        for (; t + 3 < nkt; ++t) {                                                                                     \
-            H3_WAIT_VM(4);                                                                                             \
-            if (VARIANT != 4) H3_BARRIER();                                                                            \
-            h3_stage<FULLN, VARIANT != 2 && VARIANT != 3, VARIANT != 1 && VARIANT != 3, PH>(                           \
-                acc, ah, al, bh, bl, lds + ((t + 1) & 3) * H3_STAGE, fa, fb, fo0, fo1, gp, (long)(t + 3) * H3_ROWB,    \
-                lds + ((t + 3) & 3) * H3_STAGE + sdst);                                                                \
-        }                                                                                                              \
-        for (; t + 1 < nkt; ++t) {                                                                                     \
-            if (t + 2 < nkt) H3_WAIT_VM(4); else H3_WAIT_VM(0);                                                        \
-            H3_BARRIER();                                                                                              \
-            h3_stage<FULLN, true, false, PH>(acc, ah, al, bh, bl, lds + ((t + 1) & 3) * H3_STAGE, fa, fb, fo0, fo1, gp, 0, lds); \
-        }                                                                                                              \
-        h3_stage<FULLN, false, false, PH>(acc, ah, al, bh, bl, lds, fa, fb, fo0, fo1, gp, 0, lds);                     \
-    }
-    // the two waves of a SIMD (w and w+4) issue their DMA in different halves of the stage
-    if (full_n) { if (stB) H3_RUN(true, 1) else H3_RUN(true, 0) }
-    else { if (stB) H3_RUN(false, 1) else H3_RUN(false, 0) }
+        {                                                                                                              \
+            int t = 0;                                                                                                 \
+            for (; t + 3 < nkt; ++t) {                                                                                 \
+                H3_WAIT_VM(4);                                                                                         \
+                if (VARIANT != 4) H3_BARRIER();                                                                        \
+                h3_stage<A_TR, B_TR, FULLN, VARIANT != 2 && VARIANT != 3, VARIANT != 1 && VARIANT != 3, PH>(           \
+                    acc, ah, al, bh, bl, lds + ((t + 1) & 3) * H3_STAGE, f, gp, (long)(t + 3) * gstep,                 \
+                    lds + ((t + 3) & 3) * H3_STAGE + sdst);                                                            \
+            }                                                                                                          \
+            for (; t + 1 < nkt; ++t) {                                                                                 \
+                if (t + 2 < nkt) H3_WAIT_VM(4); else H3_WAIT_VM(0);                                                    \
+                H3_BARRIER();                                                                                          \
+                h3_stage<A_TR, B_TR, FULLN, true, false, PH>(acc, ah, al, bh, bl, lds + ((t + 1) & 3) * H3_STAGE, f, gp, 0, lds); \
+            }                                                                                                          \
+            h3_stage<A_TR, B_TR, FULLN, false, false, PH>(acc, ah, al, bh, bl, lds, f, gp, 0, lds);                    \
+        }
+        // the two waves of a SIMD (w and w+4) issue their DMA in different halves of the stage
+        if (full_n) { if (stB) H3_RUN(true, 1) else H3_RUN(true, 0) }
+        else { if (stB) H3_RUN(false, 1) else H3_RUN(false, 0) }
 #undef H3_RUN
+    }
 
     // ---- epilogue: D col = l31, row = (r&3) + 8*(r>>2) + 4*h; scales of the LAST segment
-    const float* sa = g.seg[0].sa + (long)z1 * g.seg[0].strideSA + (long)z2 * g.seg[0].strideSA2;
-    const float* sb = g.seg[0].sb + (long)z1 * g.seg[0].strideSB + (long)z2 * g.seg[0].strideSB2;
+    const H3Seg& sl = g.seg[TWOSEG ? 1 : 0];
+    const int zl1 = z / sl.zdiv, zl2 = z - zl1 * sl.zdiv;
+    const float* sa = sl.sa + (long)zl1 * sl.strideSA + (long)zl2 * sl.strideSA2;
+    const float* sb = sl.sb + (long)zl1 * sl.strideSB + (long)zl2 * sl.strideSB2;
+    const int sam = sl.sa_mul, sbm = sl.sb_mul;
     if constexpr (PAIRED) {
         const int c = n0 + wn * 32 + l31;
         const auto cc = epi.col(z, c);
-        const float sc0 = sb[c], sc1 = sb[g.pair_off + c];
+        const float sc0 = sb[(long)c * sbm], sc1 = sb[(long)(g.pair_off + c) * sbm];
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm) {
             decltype(epi.row(0, 0)) rw[16];
@@ -288,7 +397,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
             for (int r = 0; r < 16; ++r) {
                 const int m = min(m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, g.M - 1);
                 rw[r] = epi.row(z, m);
-                sr[r] = sa[m];
+                sr[r] = sa[(long)m * sam];
             }
             if constexpr (epi_has_aux<Epi>::value) {
                 decltype(epi.aux(0, 0, 0, rw[0])) ax[16];
@@ -313,7 +422,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
             const int n = n0 + tn * 128 + wn * 32 + l31;
             if (n >= g.N) continue;
             const auto cc = epi.col(z, n);
-            const float sc = sb[n];
+            const float sc = sb[(long)n * sbm];
 #pragma unroll
             for (int tm = 0; tm < 4; ++tm) {
                 decltype(epi.row(0, 0)) rw[16];
@@ -322,7 +431,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
                 for (int r = 0; r < 16; ++r) {
                     const int m = min(m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, g.M - 1);
                     rw[r] = epi.row(z, m);
-                    sr[r] = sa[m];
+                    sr[r] = sa[(long)m * sam];
                 }
                 if constexpr (epi_has_aux<Epi>::value) {
                     decltype(epi.aux(0, 0, 0, rw[0])) ax[16];
@@ -345,11 +454,11 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
     }
 }
 
-template <bool PAIRED, class Epi, int VARIANT = 0>
-inline hipError_t launch_gemm_h3(H3Args g, int batches, Epi epi, hipStream_t st) {
+template <bool A_TR, bool B_TR, bool PAIRED, bool TWOSEG, class Epi, int VARIANT = 0>
+inline hipError_t launch_gemm_h3x(H3Args g, int batches, Epi epi, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_kernel<PAIRED, Epi, VARIANT>), hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_kernel<A_TR, B_TR, PAIRED, TWOSEG, Epi, VARIANT>), hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS);
         attr_set = true;
     }
     g.tiles_m = (g.M + H3_BM - 1) / H3_BM;
@@ -371,8 +480,14 @@ inline hipError_t launch_gemm_h3(H3Args g, int batches, Epi epi, hipStream_t st)
         g.mp = 0; g.gw = 1;
         grid = dim3(8 * ((batches + 7) / 8) * g.tiles_m * g.tiles_n, 1, 1);
     }
-    hipLaunchKernelGGL((gemm_h3_kernel<PAIRED, Epi, VARIANT>), grid, dim3(H3_THREADS), H3_LDS, st, g, epi);
+    hipLaunchKernelGGL((gemm_h3_kernel<A_TR, B_TR, PAIRED, TWOSEG, Epi, VARIANT>), grid, dim3(H3_THREADS), H3_LDS, st, g, epi);
     return hipGetLastError();
+}
+
+// row-major planes on both sides, one segment (nn.Linear)
+template <bool PAIRED, class Epi, int VARIANT = 0>
+inline hipError_t launch_gemm_h3(H3Args g, int batches, Epi epi, hipStream_t st) {
+    return launch_gemm_h3x<false, false, PAIRED, false, Epi, VARIANT>(g, batches, epi, st);
 }
 
 // ---- split producers ---------------------------------------------------------------------------
@@ -462,6 +577,30 @@ __global__ __launch_bounds__(256) void h3_split_rows_kernel(const float* __restr
         if (ch < nch) h3_store_chunk(pr + ch * 32, v[c], s);
     }
     if (lane == 0) scale[row] = inv;
+}
+
+// K-major producer (diagnostics / stand-alone ops): fp32 [K][N] (pitch ld floats, N % 128 == 0) -> K-major planes
+// [k][N/128][2][128] with the uniform scale s (a power of two chosen by the caller: max|x|*s < 65504).
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void h3_split_kmajor_kernel(const float* __restrict__ x, long ld, unsigned char* __restrict__ planes,
+                                                             long K, int N, float s) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;       // one thread per 8 consecutive n of one k row
+    const int per = N / 8;
+    if (i >= K * per) return;
+    const long k = i / per;
+    const int n = (int)(i - k * per) * 8;
+    const f32x4 a = ldg4(x + k * ld + n), b = ldg4(x + k * ld + n + 4);
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    f16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float xs = v[j] * s;
+        const _Float16 t = (_Float16)xs;
+        hi[j] = t; lo[j] = (_Float16)(xs - (float)t);
+    }
+    unsigned char* dst = planes + k * (4L * N) + (n / 128) * 512 + (n % 128) * 2;
+    *reinterpret_cast<f16x8*>(dst) = hi;
+    *reinterpret_cast<f16x8*>(dst + 256) = lo;
 }
 
 inline hipError_t launch_h3_split_rows(const float* x, long ld, void* planes, float* scale, long R, int K, hipStream_t st) {

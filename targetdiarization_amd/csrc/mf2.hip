@@ -886,6 +886,31 @@ int tdx_h3_split_rows(const float* x, long ld, void* planes, float* scale, long 
     hipError_t r = tdx::launch_h3_split_rows(x, ld, planes, scale, R, K, (hipStream_t)stream);
     return r == hipSuccess ? TDX_OK : tdx::fail_hip(r, __FILE__, __LINE__);
 }
+int tdx_h3_split_kmajor(const float* x, long ld, void* planes, long K, int N, float s, void* stream) {
+    if (N % 128) return tdx::fail(TDX_E_INVALID, "tdx_h3_split_kmajor: need N%128==0");
+    const long n = K * (N / 8);
+    hipLaunchKernelGGL(tdx::h3_split_kmajor_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld,
+                       (unsigned char*)planes, K, N, s);
+    hipError_t r = hipGetLastError();
+    return r == hipSuccess ? TDX_OK : tdx::fail_hip(r, __FILE__, __LINE__);
+}
+// mode bit 0: A in K-major planes [K][M] (sa = one scale), bit 1: B in K-major planes [K][N] (sb = one scale)
+int tdx_h3_gemm_x(int mode, const void* pa, const float* sa, const void* pb, const float* sb, float* c, int M, int N, int K, void* stream) {
+    if (K % 16) return tdx::fail(TDX_E_INVALID, "tdx_h3_gemm_x: need K%16==0");
+    tdx::H3Args g{};
+    const bool atr = mode & 1, btr = mode & 2;
+    g.seg[0] = tdx::h3_seg(pa, sa, atr ? 4L * M : 4L * K, pb, sb, btr ? 4L * N : 4L * K, K);
+    if (atr) g.seg[0].sa_mul = 0;
+    if (btr) g.seg[0].sb_mul = 0;
+    g.nseg = 1; g.M = M; g.N = N;
+    EpiBias e{nullptr, c, N};
+    hipError_t r;
+    if (atr && btr) r = tdx::launch_gemm_h3x<true, true, false, false>(g, 1, e, (hipStream_t)stream);
+    else if (atr) r = tdx::launch_gemm_h3x<true, false, false, false>(g, 1, e, (hipStream_t)stream);
+    else if (btr) r = tdx::launch_gemm_h3x<false, true, false, false>(g, 1, e, (hipStream_t)stream);
+    else r = tdx::launch_gemm_h3x<false, false, false, false>(g, 1, e, (hipStream_t)stream);
+    return r == hipSuccess ? TDX_OK : tdx::fail_hip(r, __FILE__, __LINE__);
+}
 int tdx_h3_gemm_variant(const void* pa, const float* sa, const void* pb, const float* sb, const float* bias, float* c, int M, int N, int K, int variant, void* stream) {
     tdx::H3Args g{};
     g.seg[0] = tdx::h3_seg(pa, sa, 4L * K, pb, sb, 4L * K, K);

@@ -75,6 +75,9 @@ struct H3Seg {
     int sa_mul, sb_mul;
     int K;                       // multiple of 16
     int zdiv;
+    // split-K over a K-major operand: batch z2 covers k rows [z2*kchunk, z2*kchunk + K) clipped to ktotal
+    // (kchunk = 0: unused); ktotal a multiple of 16
+    int kchunk, ktotal;
 };
 
 struct H3Args {
@@ -265,7 +268,8 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
     for (int s = 0; s < (TWOSEG ? 2 : 1); ++s) {
         const H3Seg& sg = g.seg[TWOSEG ? s : 0];
         const int z1 = z / sg.zdiv, z2 = z - z1 * sg.zdiv;
-        const int nkt = sg.K / H3_BK;
+        const int nkt = (sg.kchunk ? max(0, min(sg.K, sg.ktotal - z2 * sg.kchunk)) : sg.K) / H3_BK;
+        if (nkt == 0) continue;      // (block-uniform) nothing to add from this segment
         const unsigned char* gp[4];
         long gstep;
         if (!stB) {
@@ -318,17 +322,25 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
                 const int c = PAIRED ? (tn == 0 ? n0 + wn * 32 + l31 : g.pair_off + n0 + wn * 32 + l31) : min(n0 + tn * 128 + wn * 32 + l31, g.N - 1);
                 cf[tn] = sb0[(long)c * s0.sb_mul] / sb1[(long)c * sg.sb_mul];
             }
-#pragma unroll
-            for (int tm = 0; tm < 4; ++tm) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = min(m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, g.M - 1);
-                    const float rf = sa0[(long)m * s0.sa_mul] / sa1[(long)m * sg.sa_mul];
-                    acc[tm][0][r] *= rf * cf[0];
-                    acc[tm][1][r] *= rf * cf[1];
-                }
-                asm volatile("" ::: "memory");
+            // row factors through LDS (the stage buffers are idle here): 256 floats, then 16 ds_read_b128 per lane
+            __syncthreads();
+            float* rfl = reinterpret_cast<float*>(lds);
+            if (tid < 256) {
+                const int m = min(m0 + tid, g.M - 1);
+                rfl[tid] = sa0[(long)m * s0.sa_mul] / sa1[(long)m * sg.sa_mul];
             }
+            __syncthreads();
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 rf = *reinterpret_cast<const f32x4*>(rfl + wm * 128 + tm * 32 + 8 * j + 4 * h);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc[tm][0][4 * j + i] *= rf[i] * cf[0];
+                        acc[tm][1][4 * j + i] *= rf[i] * cf[1];
+                    }
+                }
             __syncthreads();      // every wave is done with the stage buffers the next DMA overwrites
         }
 

@@ -7,6 +7,7 @@
 // the caller's stream (no allocation, no sync => hipGraph-capturable).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -70,6 +71,26 @@ struct EpiAttnGate { // o = (att_u*v)*sigmoid(att_v*u)                       mos
         } else {
             o[rw * E + c] = (au * vu2.x) * sigmoidf_acc(av * vu2.y);
         }
+    }
+};
+struct EpiAttnGateP { // the same gate with v, u read back from the K-major split-f16 planes (v = (hi + lo) * inv)
+    const unsigned char* vuP; const float* inv; float* o; int G; int S; int Sp; int E;
+    __device__ EpiNone col(int, int) const { return EpiNone{}; }
+    __device__ long2 row(int z, int m) const {     // (token row of o, padded row of the planes), or -1 for group padding
+        const int b = z / G, s = (z % G) * 256 + m;
+        return s < S ? make_long2((long)b * S + s, (long)b * Sp + s) : make_long2(-1L, -1L);
+    }
+    __device__ float2 aux(int, int, int c, long2 rw) const {
+        if (rw.x < 0) return make_float2(0.f, 0.f);
+        const unsigned char* p = vuP + rw.y * (8L * E) + (c >> 7) * 512 + (c & 127) * 2;      // u: + (E/128)*512
+        const _Float16 vh = *reinterpret_cast<const _Float16*>(p), vl = *reinterpret_cast<const _Float16*>(p + 256);
+        const _Float16 uh = *reinterpret_cast<const _Float16*>(p + (E >> 7) * 512), ul = *reinterpret_cast<const _Float16*>(p + (E >> 7) * 512 + 256);
+        const float k = inv[0];
+        return make_float2(((float)vh + (float)vl) * k, ((float)uh + (float)ul) * k);
+    }
+    __device__ void store2(int, int, int c, float av, float au, long2 rw, EpiNone, float2 vu2) const {
+        if (rw.x < 0) return;
+        o[rw.x * E + c] = (au * vu2.x) * sigmoidf_acc(av * vu2.y);
     }
 };
 struct EpiBiasPrelu { // prelu_scalar(acc + b[n])                            mossformer_block.py:405-408
@@ -182,6 +203,10 @@ struct LayerW {
     const float *W1, *b1, *a1, *ln1g, *ln1b, *Wuv, *buv, *cw_uv, *Wl, *bl, *Wp, *w1T, *w2T, *ing, *inb, *pre, *ln2g, *ln2b, *W2, *b2;
     // nn.Linear weights as split-f16 planes + row scales (gemm_h3.hpp), made once at create
     H3W hWhq, hWo, hW1, hWuv, hWl, hWp, hW2;
+    // static power-of-two scales of the K-major planes of v|u and lin_k (bounds from the weights, see tdx_mf2_create):
+    // sv_* multiplies the value before the f16 split, st points at the device copy of {1/sv_vu, 1/sv_lk}
+    float sv_vu, sv_lk;
+    const float* st;
 };
 
 }  // namespace
@@ -192,6 +217,7 @@ struct tdx_mf2 {
     float* dev_weights;
     size_t n_weights;
     unsigned char* dev_planes;      // split-f16 planes + scales of every nn.Linear weight
+    float* dev_static;              // [L][2] inverse static scales
     H3W hWenc, hWout;
     std::vector<LayerW> layers;
     const float *encT, *gn1g, *gn1b, *Wenc, *pe_scale, *inv_freq, *rot_freqs, *lnfg, *lnfb, *gn2g, *gn2b, *prelu, *Wout, *bout,
@@ -209,7 +235,7 @@ struct Plan {
     int B, T, S, G, Sp, splits, kchunk, nblk_enc, nblk_gn, nchunk1, nchunk2;
     long M;
     // offsets in floats
-    size_t E, z, x, rs, hid, vu, qk4, Abuf, slab, kvu, o, t, hraw, h, hp, hs, uvpre, uv, f, p, c1, c2, pe, rc, rsn, stat,
+    size_t E, z, x, rs, hid, vu, qk4, Abuf, slab, kvu, o, t, hraw, h, hp, hs, vuP, AbufP, Asc, qks, KvuP, kvus, uvpre, uv, f, p, c1, c2, pe, rc, rsn, stat,
         part, tap0, tap1, mask, total;
 };
 
@@ -242,6 +268,15 @@ bool make_plan(const tdx_mf2* h, int B, int T, Plan& P) {
     P.hraw = take(M * INNER); P.h = take(M * INNER);
     P.hp = take(M * 1024);      // split-f16 planes of the current GEMM's A operand (<= 1024 channels: 4 KB per row)
     P.hs = take(M);             // and its row scales
+    // attention on the x3 core: K-major planes of v|u (pad rows zero), row-major planes + row scales of the
+    // relu^2 similarity, row scales of quad_q / lin_q / quad_k (their planes live in the qk4 slots), K-major
+    // planes of Kvu with one scale per sample (+ its atomicMax word)
+    P.vuP = take((size_t)B * P.Sp * HID);
+    P.AbufP = take((size_t)B * P.G * 65536);
+    P.Asc = take((size_t)B * P.Sp);
+    P.qks = take((size_t)3 * B * P.Sp);
+    P.KvuP = take((size_t)B * QK * HID);
+    P.kvus = take((size_t)2 * B + 64);
     P.uvpre = take(M * C); P.uv = take(M * C); P.f = take(M * INNER); P.p = take(M * INNER);
     P.c1 = take(M * INNER); P.c2 = take(M * INNER);
     P.pe = take((size_t)P.S * C); P.rc = take((size_t)P.S * 16); P.rsn = take((size_t)P.S * 16);
@@ -267,12 +302,12 @@ inline dim3 rows4(long M) { return dim3((unsigned)((M + 3) / 4)); }
 // conv17 launch helper
 template <int MODE>
 int launch_conv17(Conv17Args a, int B, hipStream_t st) {
-    constexpr int TPT = MODE == 2 ? 32 : 128;
+    constexpr int TPT = (MODE == 2 || MODE == 3) ? 32 : 128;
     const int quads = a.C / 4;
     const int qb = quads >= 256 ? 256 : quads;      // 256, 128 or 32
     const int ty = 256 / qb;
     dim3 block(qb, ty);
-    const int s_lim = MODE == 2 ? a.Sp : a.S;
+    const int s_lim = MODE >= 2 ? a.Sp : a.S;
     dim3 grid(quads / qb, (s_lim + ty * TPT - 1) / (ty * TPT), B);
     hipLaunchKernelGGL((conv17_kernel<MODE, TPT>), grid, block, 0, st, a);
     LAUNCH_CHECK();
@@ -315,6 +350,66 @@ int attention_core(const float* qk4, const float* vu, int B, int S, int E, int s
         if (E % 128 == 0) r = launch_gemm_x6<true, true, false>(g, B * G, e, st);       // split-bf16 x6 core (256-row group = one M tile)
         else r = launch_gemm<false, true, true, false>(g, B * G, e, st);                // fp32-MFMA core (test shapes with E % 128 != 0)
         if (r != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    }
+    return TDX_OK;
+}
+
+// The same attention on the split-f16 x3 core (gemm_h3.hpp), E = 1024:
+//   qkP : the four heads as planes in [4][B][Sp] x 512 B slots (conv17 MODE 3): quad_q, lin_q, quad_k row-major
+//         with row scales qks[3][B*Sp]; lin_k K-major with the static scale st[1]
+//   vuP : K-major planes [B][Sp][16][2][128] of v|u with the static scale st[0] (pad rows zero); vu: fp32 (gate)
+int attention_core_h3(const unsigned char* qkP, const float* qks, const unsigned char* vuP, const float* vu, const float* st,
+                      int B, int S, int splits, int kchunk, float* Abuf, unsigned char* AbufP, float* Asc, float* slab, float* kvu,
+                      unsigned char* KvuP, float* kvus, float* o, hipStream_t st_) {
+    constexpr int E = 1024;
+    const int G = (S + 255) / 256, Sp = G * 256;
+    const long hs = (long)B * Sp;                 // rows per head
+    const unsigned char *quad_q = qkP, *lin_q = qkP + hs * 512, *quad_k = qkP + 2 * hs * 512, *lin_k = qkP + 3 * hs * 512;
+    const float *sq = qks, *slq = qks + hs, *sk = qks + 2 * hs;
+    {   // A = relu(q k^T / 256)^2 per group, then its rows as planes                 mossformer_block.py:256-262
+        tdx::H3Args g{};
+        g.seg[0] = tdx::h3_seg(quad_q, sq, 512, quad_k, sk, 512, QK);
+        g.seg[0].strideA = 256L * 512; g.seg[0].strideB = 256L * 512; g.seg[0].strideSA = 256; g.seg[0].strideSB = 256;
+        g.nseg = 1; g.M = 256; g.N = 256;
+        EpiQuadSim e{Abuf, G, S, 1.0f / 256.0f};
+        if (tdx::launch_gemm_h3x<false, false, false, false>(g, B * G, e, st_) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+        if (tdx::launch_h3_split_rows(Abuf, 256, AbufP, Asc, (long)B * Sp, 256, st_) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    }
+    {   // KvuT[b][ch][d] = (1/S) sum_t vu[t][ch] lin_k[t][d], split over token chunks     mossformer_block.py:286,289
+        tdx::H3Args g{};
+        g.seg[0] = tdx::h3_seg(vuP, st, 4L * 2 * E, lin_k, st + 1, 512, kchunk);
+        g.seg[0].sa_mul = 0; g.seg[0].sb_mul = 0;
+        g.seg[0].zdiv = splits;
+        g.seg[0].strideA = (long)Sp * 4 * 2 * E; g.seg[0].strideA2 = (long)kchunk * 4 * 2 * E;
+        g.seg[0].strideB = (long)Sp * 512; g.seg[0].strideB2 = (long)kchunk * 512;
+        g.seg[0].kchunk = kchunk; g.seg[0].ktotal = Sp;
+        g.nseg = 1; g.M = 2 * E; g.N = QK;
+        EpiStore e{slab, (long)QK, (long)QK * 2 * E};
+        if (tdx::launch_gemm_h3x<true, true, false, false>(g, B * splits, e, st_) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+        const long per = (long)QK * 2 * E;
+        unsigned* mx = reinterpret_cast<unsigned*>(kvus + B);
+        if (hipMemsetAsync(mx, 0, (size_t)B * sizeof(unsigned), st_) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+        hipLaunchKernelGGL(kvu_reduce_t_kernel, dim3((unsigned)((per / 4 + 255) / 256), B), dim3(256), 0, st_, slab, kvu, splits, per, (float)S, mx);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(kvu_planes_kernel, dim3((unsigned)((128 * (2 * E / 8) + 255) / 256), B), dim3(256), 0, st_, kvu, mx, KvuP, kvus, 2 * E);
+        LAUNCH_CHECK();
+    }
+    {   // [A | lin_q] x [VU ; Kvu] with the gate epilogue                                mossformer_block.py:269-294, :217
+        tdx::H3Args g{};
+        g.seg[0] = tdx::h3_seg(AbufP, Asc, 1024, vuP, st, 4L * 2 * E, 256);
+        g.seg[0].sb_mul = 0; g.seg[0].zdiv = G;
+        g.seg[0].strideA = (long)G * 256 * 1024; g.seg[0].strideA2 = 256L * 1024;
+        g.seg[0].strideSA = (long)G * 256; g.seg[0].strideSA2 = 256;
+        g.seg[0].strideB = (long)Sp * 4 * 2 * E; g.seg[0].strideB2 = 256L * 4 * 2 * E;
+        g.seg[1] = tdx::h3_seg(lin_q, slq, 512, KvuP, kvus, 4L * 2 * E, QK);
+        g.seg[1].sb_mul = 0; g.seg[1].zdiv = G;
+        g.seg[1].strideA = (long)Sp * 512; g.seg[1].strideA2 = 256L * 512;
+        g.seg[1].strideSA = Sp; g.seg[1].strideSA2 = 256;
+        g.seg[1].strideB = (long)QK * 4 * 2 * E; g.seg[1].strideB2 = 0;
+        g.seg[1].strideSB = 1; g.seg[1].strideSB2 = 0;
+        g.nseg = 2; g.M = 256; g.N = E; g.pair_off = E;
+        EpiAttnGate e{vu, o, nullptr, nullptr, G, S, E};      // (EpiAttnGateP, gate operands read back from the planes, measured 25 % slower)
+        if (tdx::launch_gemm_h3x<false, true, true, true>(g, B * G, e, st_) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
     }
     return TDX_OK;
 }
@@ -402,6 +497,8 @@ int tdx_mf2_create(const tdx_mf2_config* cfg, const void* blob, size_t blob_byte
         if (w) for (int c = 0; c < Cc; ++c) for (int t = 0; t < k; ++t) host[o + (size_t)t * Cc + c] = w[(size_t)c * k + t];
         return o;
     };
+    std::vector<float> stat_host((size_t)L * 2, 1.f);
+    std::vector<float> sv_host((size_t)L * 2, 1.f);
     struct Off { size_t Whq, ghq, bhq, cw_h, cw_qk, gamma, beta, Wo, go, bo, cw_o, W1, b1, a1, ln1g, ln1b, Wuv, buv, cw_uv, Wl, bl, Wp, w1T, w2T, ing, inb, pre, ln2g, ln2b, W2, b2; };
     std::vector<Off> offs(L);
     const std::string PFX = "mask_net.mdl.intra_mdl.mossformerM.";
@@ -425,8 +522,42 @@ int tdx_mf2_create(const tdx_mf2_config* cfg, const void* blob, size_t blob_byte
         for (int i = 0; i < HQ; ++i) host[o.bhq + i] = i < HID ? bh[i] : bq[i - HID];
         o.cw_h = push_tapmajor(cwh, HID, 17);
         o.cw_qk = push_tapmajor(cwq, QK, 17);
-        o.gamma = push(get(p + "qk_offset_scale.gamma", 4 * QK), 4 * QK);
-        o.beta = push(get(p + "qk_offset_scale.beta", 4 * QK), 4 * QK);
+        const float* gam = get(p + "qk_offset_scale.gamma", 4 * QK);
+        const float* bet = get(p + "qk_offset_scale.beta", 4 * QK);
+        o.gamma = push(gam, 4 * QK);
+        o.beta = push(bet, 4 * QK);
+        if (!ok) break;
+        {
+            // Static bounds for the K-major planes (gemm_h3.hpp).  After ScaleNorm the (shifted) row has norm
+            // <= sqrt(512), so |x_hat . W_n| <= sqrt(512) |g| ||W_n|| (Cauchy-Schwarz) and |silu(p)| <= |p|;
+            // the depthwise conv + identity multiplies by at most 1 + sum_t |w_ct|; OffsetScale by |gamma|,
+            // + |beta|; the rotary pair rotation by sqrt(2).
+            auto ybound = [&](const float* W, const float* bias, int rows, float gs) {
+                double best = 0;
+                for (int n = 0; n < rows; ++n) {
+                    double q2 = 0;
+                    for (int k = 0; k < C; ++k) q2 += (double)W[(size_t)n * C + k] * W[(size_t)n * C + k];
+                    best = std::max(best, std::sqrt(512.0) * std::fabs(gs) * std::sqrt(q2) + std::fabs(bias[n]));
+                }
+                return best;
+            };
+            auto wsum = [&](const float* cw, int rows) {
+                double best = 0;
+                for (int c = 0; c < rows; ++c) {
+                    double a = 1.0;
+                    for (int t = 0; t < 17; ++t) a += std::fabs(cw[(size_t)c * 17 + t]);
+                    best = std::max(best, a);
+                }
+                return best;
+            };
+            const double vub = wsum(cwh, HID) * ybound(Wh, bh, HID, gh[0]);
+            double gmax = 0, bmax = 0;
+            for (int i = 0; i < QK; ++i) { gmax = std::max(gmax, (double)std::fabs(gam[3 * QK + i])); bmax = std::max(bmax, (double)std::fabs(bet[3 * QK + i])); }
+            const double lkb = (wsum(cwq, QK) * ybound(Wq, bq, QK, gq[0]) * gmax + bmax) * std::sqrt(2.0);
+            auto pow2scale = [](double bound) { int e = (int)std::floor(std::log2(std::max(bound, 1e-30))); e = std::max(-100, std::min(100, e)); return std::ldexp(1.0, 14 - e); };
+            sv_host[l * 2] = (float)pow2scale(vub); sv_host[l * 2 + 1] = (float)pow2scale(lkb);
+            stat_host[l * 2] = 1.0f / sv_host[l * 2]; stat_host[l * 2 + 1] = 1.0f / sv_host[l * 2 + 1];
+        }
         o.Wo = push(get(p + "to_out.mdl.1.weight", (size_t)C * 1024), (size_t)C * 1024);
         const float* go = get(p + "to_out.mdl.0.g", 1);
         o.go = host.size(); host.resize(host.size() + al(C));
@@ -523,7 +654,7 @@ int tdx_mf2_create(const tdx_mf2_config* cfg, const void* blob, size_t blob_byte
     if (e != hipSuccess) { hipFree(dev); return tdx::fail_hip(e, __FILE__, __LINE__); }
 
     tdx_mf2* h = new tdx_mf2();
-    h->dev_planes = nullptr;
+    h->dev_planes = nullptr; h->dev_static = nullptr;
     h->device = device; h->L = L; h->dev_weights = dev; h->n_weights = host.size(); h->taps = 0; h->ev_used = 0;
     h->layers.resize(L);
     for (int l = 0; l < L; ++l) {
@@ -539,6 +670,10 @@ int tdx_mf2_create(const tdx_mf2_config* cfg, const void* blob, size_t blob_byte
     h->inv_freq = dev + invf; h->rot_freqs = dev + rotf; h->lnfg = dev + lnfg; h->lnfb = dev + lnfb; h->gn2g = dev + gn2g;
     h->gn2b = dev + gn2b; h->prelu = dev + prelu; h->Wout = dev + Wout; h->bout = dev + bout; h->Wtg = dev + Wtg; h->btg = dev + btg;
     h->Wdec1 = dev + Wdec1; h->decT = dev + decT;
+    e = hipMalloc(&h->dev_static, stat_host.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(h->dev_static, stat_host.data(), stat_host.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(dev); delete h; return tdx::fail_hip(e, __FILE__, __LINE__); }
+    for (int l = 0; l < L; ++l) { h->layers[l].sv_vu = sv_host[l * 2]; h->layers[l].sv_lk = sv_host[l * 2 + 1]; h->layers[l].st = h->dev_static + l * 2; }
     // ---- split every nn.Linear weight [N][K] into f16 planes + row scales, once
     {
         struct Job { const float* w; int N, K; H3W* dst; };
@@ -573,6 +708,7 @@ int tdx_mf2_destroy(tdx_mf2* h) {
     if (!h) return TDX_OK;
     if (h->dev_weights) hipFree(h->dev_weights);
     if (h->dev_planes) hipFree(h->dev_planes);
+    if (h->dev_static) hipFree(h->dev_static);
     for (auto e : h->ev0) hipEventDestroy(e);
     for (auto e : h->ev1) hipEventDestroy(e);
     delete h;
@@ -648,6 +784,8 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
           *c1 = ws + P.c1, *c2 = ws + P.c2, *pe = ws + P.pe, *rc = ws + P.rc, *rsn = ws + P.rsn, *stat = ws + P.stat;
     double* part = (double*)(ws + P.part);
     unsigned char* hp = (unsigned char*)(ws + P.hp);
+    unsigned char *vuP = (unsigned char*)(ws + P.vuP), *AbufP = (unsigned char*)(ws + P.AbufP), *KvuP = (unsigned char*)(ws + P.KvuP);
+    float *Asc = ws + P.Asc, *qks = ws + P.qks, *kvus = ws + P.kvus;
     float* gnstat = stat;               // [B][2]
     float* stat1 = stat + al(2 * B);    // [B][256][2]
     float* stat2 = stat1 + (size_t)B * 512;
@@ -680,13 +818,16 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
         {
             Conv17Args a{};
             a.in = hid; a.ld_in = HQ; a.col0 = 0; a.wT = w.cw_h; a.C = HID; a.out = vu; a.ld_out = HID; a.S = S; a.Sp = Sp;
-            TRY(launch_conv17<0>(a, B, st));
+            a.hp = vuP; a.sv = w.sv_vu;
+            TRY(launch_conv17<4>(a, B, st));          // v|u in fp32 (gate operands) and as K-major planes (GEMM operands)
             Conv17Args q{};
             q.in = hid; q.ld_in = HQ; q.col0 = HID; q.wT = w.cw_qk; q.C = QK; q.S = S; q.Sp = Sp; q.gamma = w.gamma; q.beta = w.beta;
-            q.rot_cos = rc; q.rot_sin = rsn; q.qk4 = qk4; q.head_stride = (long)B * Sp * QK;
-            TRY(launch_conv17<2>(q, B, st));
+            q.rot_cos = rc; q.rot_sin = rsn; q.head_stride = (long)B * Sp * QK;
+            q.hp = (unsigned char*)qk4; q.hs = qks; q.sv = w.sv_lk;
+            TRY(launch_conv17<3>(q, B, st));          // the four heads as planes
         }
-        TRY(attention_core(qk4, vu, B, S, 1024, P.splits, P.kchunk, Abuf, slab, kvu, o, nullptr, nullptr, st));
+        TRY(attention_core_h3((const unsigned char*)qk4, qks, vuP, vu, w.st, B, S, P.splits, P.kchunk, Abuf, AbufP, Asc, slab, kvu, KvuP, kvus,
+                              o, st));
         hipLaunchKernelGGL((rowscale_split_kernel<1024, false>), rows4(M), dim3(256), 0, st, o, rs, hp, hs, M, S);
         LAUNCH_CHECK();
         TRY(linear_h3(hp, hs, (int)M, w.hWo, C, 1024, EpiHidden{rs, w.go, w.bo, t, C}, st));

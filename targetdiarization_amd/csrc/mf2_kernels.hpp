@@ -373,6 +373,52 @@ __global__ __launch_bounds__(256) void fsmn_tail_kernel(const float* __restrict_
     if (lane == 0) hs[m] = inv;
 }
 
+// x3 path: kvuT[b][ch][d] = (sum_sp slab[b][sp][ch][d]) / S in fp32, and max |kvuT[b]| as float bits (atomicMax;
+// mx must be zeroed before).  Then kvu_planes_kernel re-writes it as K-major planes KvuP[b][d][16][2][128]
+// with one exact power-of-two scale per sample (the B operand of the attention GEMM's linear segment).
+__global__ __launch_bounds__(256) void kvu_reduce_t_kernel(const float* __restrict__ slab, float* __restrict__ kvu, int splits, long per,
+                                                            float S, unsigned* __restrict__ mx) {
+    const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    float m = 0.f;
+    if (i4 * 4 < per) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sp = 0; sp < splits; ++sp) {
+            const float4 v = *reinterpret_cast<const float4*>(slab + ((long)b * splits + sp) * per + i4 * 4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        const float inv = 1.0f / S;
+        acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+        *reinterpret_cast<float4*>(kvu + (long)b * per + i4 * 4) = acc;
+        m = h3_absmax4(acc);
+    }
+    m = h3_wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(mx + b, __float_as_uint(m));
+}
+__global__ __launch_bounds__(256) void kvu_planes_kernel(const float* __restrict__ kvu, const unsigned* __restrict__ mx,
+                                                          unsigned char* __restrict__ planes, float* __restrict__ scale, int E2) {
+    // thread = (d, 8 consecutive ch); kvu[b] is [E2 ch][128 d]
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int per = E2 / 8;
+    if (i >= 128 * per) return;
+    const int d = i / per, ch = (i - d * per) * 8;
+    float inv;
+    const float s = h3_row_scale(__uint_as_float(mx[b]), inv);
+    const float* src = kvu + (long)b * E2 * 128 + (long)ch * 128 + d;
+    f16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float xs = src[j * 128] * s;
+        const _Float16 t = (_Float16)xs;
+        hi[j] = t; lo[j] = (_Float16)(xs - (float)t);
+    }
+    unsigned char* dst = planes + ((long)b * 128 + d) * (4L * E2) + (ch >> 7) * 512 + (ch & 127) * 2;
+    *reinterpret_cast<f16x8*>(dst) = hi;
+    *reinterpret_cast<f16x8*>(dst + 256) = lo;
+    if (i == 0) scale[b] = inv;
+}
+
 // Kvu[b][d][c] = (sum_sp slab[b][sp][d][c]) / S      (mossformer_block.py:286,289)
 __global__ __launch_bounds__(256) void kvu_reduce_kernel(const float* __restrict__ slab, float* __restrict__ kvu,
                                                           int splits, long per, float S) {

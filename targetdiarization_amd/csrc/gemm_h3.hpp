@@ -592,17 +592,29 @@ __global__ __launch_bounds__(256) void h3_split_rows_kernel(const float* __restr
 }
 
 // K-major producer (diagnostics / stand-alone ops): fp32 [K][N] (pitch ld floats, N % 128 == 0) -> K-major planes
-// [k][N/128][2][128] with the uniform scale s (a power of two chosen by the caller: max|x|*s < 65504).
+// [k][N/128][2][128] with one scale: s (a power of two chosen by the caller: max|x|*s < 65504), or, when mx is
+// given, the exact exponent-aligned scale of the float whose bits are mx[0] (its inverse is written to inv[0]).
+// With Sp > 0 the k rows are [b][Sp] and row (b, t) reads source row b*S + t, zero for t >= S (group padding).
 template <int UNUSED = 0>
 __global__ __launch_bounds__(256) void h3_split_kmajor_kernel(const float* __restrict__ x, long ld, unsigned char* __restrict__ planes,
-                                                             long K, int N, float s) {
+                                                             long K, int N, float s, const unsigned* __restrict__ mx,
+                                                             float* __restrict__ inv, int S, int Sp) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;       // one thread per 8 consecutive n of one k row
     const int per = N / 8;
     if (i >= K * per) return;
     const long k = i / per;
     const int n = (int)(i - k * per) * 8;
-    const f32x4 a = ldg4(x + k * ld + n), b = ldg4(x + k * ld + n + 4);
-    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    if (mx) {
+        float iv;
+        s = h3_row_scale(__uint_as_float(mx[0]), iv);
+        if (i == 0) inv[0] = iv;
+    }
+    long src = k;
+    bool ok = true;
+    if (Sp > 0) { const long b = k / Sp; const int t = (int)(k - b * Sp); ok = t < S; src = b * S + t; }
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b4 = {0.f, 0.f, 0.f, 0.f};
+    if (ok) { a = ldg4(x + src * ld + n); b4 = ldg4(x + src * ld + n + 4); }
+    const float v[8] = {a[0], a[1], a[2], a[3], b4[0], b4[1], b4[2], b4[3]};
     f16x8 hi, lo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -613,6 +625,15 @@ __global__ __launch_bounds__(256) void h3_split_kmajor_kernel(const float* __res
     unsigned char* dst = planes + k * (4L * N) + (n / 128) * 512 + (n % 128) * 2;
     *reinterpret_cast<f16x8*>(dst) = hi;
     *reinterpret_cast<f16x8*>(dst + 256) = lo;
+}
+
+// max |x| over n floats as float bits (atomicMax; mx zeroed by the caller)
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void h3_absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ mx) {
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    m = h3_wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(mx, __float_as_uint(m));
 }
 
 inline hipError_t launch_h3_split_rows(const float* x, long ld, void* planes, float* scale, long R, int K, hipStream_t st) {

@@ -359,9 +359,8 @@ int attention_core(const float* qk4, const float* vu, int B, int S, int E, int s
 //         with row scales qks[3][B*Sp]; lin_k K-major with the static scale st[1]
 //   vuP : K-major planes [B][Sp][16][2][128] of v|u with the static scale st[0] (pad rows zero); vu: fp32 (gate)
 int attention_core_h3(const unsigned char* qkP, const float* qks, const unsigned char* vuP, const float* vu, const float* st,
-                      int B, int S, int splits, int kchunk, float* Abuf, unsigned char* AbufP, float* Asc, float* slab, float* kvu,
-                      unsigned char* KvuP, float* kvus, float* o, hipStream_t st_) {
-    constexpr int E = 1024;
+                      int B, int S, int E, int splits, int kchunk, float* Abuf, unsigned char* AbufP, float* Asc, float* slab, float* kvu,
+                      unsigned char* KvuP, float* kvus, float* o, float* att_v, float* att_u, hipStream_t st_) {
     const int G = (S + 255) / 256, Sp = G * 256;
     const long hs = (long)B * Sp;                 // rows per head
     const unsigned char *quad_q = qkP, *lin_q = qkP + hs * 512, *quad_k = qkP + 2 * hs * 512, *lin_k = qkP + 3 * hs * 512;
@@ -408,7 +407,7 @@ int attention_core_h3(const unsigned char* qkP, const float* qks, const unsigned
         g.seg[1].strideB = (long)QK * 4 * 2 * E; g.seg[1].strideB2 = 0;
         g.seg[1].strideSB = 1; g.seg[1].strideSB2 = 0;
         g.nseg = 2; g.M = 256; g.N = E; g.pair_off = E;
-        EpiAttnGate e{vu, o, nullptr, nullptr, G, S, E};      // (EpiAttnGateP, gate operands read back from the planes, measured 25 % slower)
+        EpiAttnGate e{vu, o, att_v, att_u, G, S, E};      // (EpiAttnGateP, gate operands read back from the planes, measured 25 % slower)
         if (tdx::launch_gemm_h3x<false, true, true, true>(g, B * G, e, st_) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
     }
     return TDX_OK;
@@ -826,8 +825,8 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
             q.hp = (unsigned char*)qk4; q.hs = qks; q.sv = w.sv_lk;
             TRY(launch_conv17<3>(q, B, st));          // the four heads as planes
         }
-        TRY(attention_core_h3((const unsigned char*)qk4, qks, vuP, vu, w.st, B, S, P.splits, P.kchunk, Abuf, AbufP, Asc, slab, kvu, KvuP, kvus,
-                              o, st));
+        TRY(attention_core_h3((const unsigned char*)qk4, qks, vuP, vu, w.st, B, S, 1024, P.splits, P.kchunk, Abuf, AbufP, Asc, slab, kvu, KvuP,
+                              kvus, o, nullptr, nullptr, st));
         hipLaunchKernelGGL((rowscale_split_kernel<1024, false>), rows4(M), dim3(256), 0, st, o, rs, hp, hs, M, S);
         LAUNCH_CHECK();
         TRY(linear_h3(hp, hs, (int)M, w.hWo, C, 1024, EpiHidden{rs, w.go, w.bo, t, C}, st));
@@ -927,6 +926,10 @@ static void attn_plan(int B, int S, int E, int& splits, int& kchunk, size_t& qk4
     auto take = [&](size_t nn) { size_t o = off; off += al(nn); return o; };
     qk4 = take((size_t)4 * B * Sp * QK); vu = take((size_t)B * S * 2 * E); Abuf = take((size_t)B * G * 65536);
     slab = take((size_t)B * splits * QK * 2 * E); kvu = take((size_t)B * QK * 2 * E);
+    if (E % 128 == 0) {   // split-f16 x3 path (as the model): planes of the heads, of v|u, of the similarity and of Kvu, and scales
+        take((size_t)4 * B * Sp * QK); take((size_t)B * Sp * 2 * E); take((size_t)B * G * 65536); take((size_t)B * QK * 2 * E);
+        take((size_t)4 * B * Sp); take((size_t)2 * B + 64); take(64);
+    }
     total = off;
 }
 
@@ -957,7 +960,40 @@ int tdx_cal_attention(const float* quad_q, const float* lin_q, const float* quad
     const long M = (long)B * S;
     hipLaunchKernelGGL(concat_vu_kernel, dim3((unsigned)((M * 2 * E + 255) / 256)), dim3(256), 0, st, v, u, ws + ovu, M, E);
     LAUNCH_CHECK();
-    return attention_core(ws + oq, ws + ovu, B, S, E, splits, kchunk, ws + oA, ws + oslab, ws + okvu, nullptr, att_v, att_u, st);
+    if (E % 128) return attention_core(ws + oq, ws + ovu, B, S, E, splits, kchunk, ws + oA, ws + oslab, ws + okvu, nullptr, att_v, att_u, st);
+    // ---- the model's path (split-f16 x3 core): planes made here by the generic producers, with the exact maxima of
+    // lin_k and v|u standing in for the model's static bounds
+    float* p = ws + okvu + al((size_t)B * QK * 2 * E);
+    unsigned char* qkP = (unsigned char*)p; p += al((size_t)4 * B * Sp * QK);
+    unsigned char* vuP = (unsigned char*)p; p += al((size_t)B * Sp * 2 * E);
+    unsigned char* AbufP = (unsigned char*)p; p += al((size_t)B * G * 65536);
+    unsigned char* KvuP = (unsigned char*)p; p += al((size_t)B * QK * 2 * E);
+    float* qks = p; p += al((size_t)4 * B * Sp);
+    float* kvus = p; p += al((size_t)2 * B + 64);
+    float* stt = p;                       // [0..1] inverse scales of v|u, lin_k ; [2..3] their maxima (bits)
+    float* Asc = qks + 3L * B * Sp;
+    unsigned* mx = reinterpret_cast<unsigned*>(stt + 2);
+    if (hipMemsetAsync(mx, 0, 2 * sizeof(unsigned), st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    hipLaunchKernelGGL(tdx::h3_absmax_kernel<0>, dim3(1024), dim3(256), 0, st, ws + ovu, M * 2 * E, mx);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(tdx::h3_absmax_kernel<0>, dim3(1024), dim3(256), 0, st, ws + oq + 3 * hs, hs, mx + 1);
+    LAUNCH_CHECK();
+    for (int i = 0; i < 3; ++i)
+        if (tdx::launch_h3_split_rows(ws + oq + i * hs, QK, qkP + (size_t)i * hs * 4, qks + (long)i * B * Sp, (long)B * Sp, QK, st) != hipSuccess)
+            return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    {
+        const long K = (long)B * Sp;
+        long n = K * (QK / 8);
+        hipLaunchKernelGGL(tdx::h3_split_kmajor_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws + oq + 3 * hs, (long)QK,
+                           qkP + (size_t)3 * hs * 4, K, QK, 1.0f, mx + 1, stt + 1, 0, 0);
+        LAUNCH_CHECK();
+        n = K * (2 * E / 8);
+        hipLaunchKernelGGL(tdx::h3_split_kmajor_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws + ovu, 2L * E, vuP, K, 2 * E, 1.0f,
+                           mx, stt, S, Sp);
+        LAUNCH_CHECK();
+    }
+    return attention_core_h3(qkP, qks, vuP, ws + ovu, stt, B, S, E, splits, kchunk, ws + oA, AbufP, Asc, ws + oslab, ws + okvu, KvuP, kvus,
+                             nullptr, att_v, att_u, st);
 }
 
 size_t tdx_dilated_dense_net_workspace_bytes(int B, int S) {
@@ -1031,7 +1067,7 @@ int tdx_h3_split_kmajor(const float* x, long ld, void* planes, long K, int N, fl
     if (N % 128) return tdx::fail(TDX_E_INVALID, "tdx_h3_split_kmajor: need N%128==0");
     const long n = K * (N / 8);
     hipLaunchKernelGGL(tdx::h3_split_kmajor_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld,
-                       (unsigned char*)planes, K, N, s);
+                       (unsigned char*)planes, K, N, s, (const unsigned*)nullptr, (float*)nullptr, 0, 0);
     hipError_t r = hipGetLastError();
     return r == hipSuccess ? TDX_OK : tdx::fail_hip(r, __FILE__, __LINE__);
 }

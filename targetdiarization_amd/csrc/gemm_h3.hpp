@@ -265,13 +265,9 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
     }
     const bool full_n = PAIRED || (n0 + 128 < g.N);
 
-    for (int s = 0; s < (TWOSEG ? 2 : 1); ++s) {
-        const H3Seg& sg = g.seg[TWOSEG ? s : 0];
+    // per-lane DMA source pointers of a segment's first k-tile (gp) and their advance per k-tile (gstep)
+    auto setup = [&](const H3Seg& sg, const unsigned char* (&gp)[4], long& gstep) {
         const int z1 = z / sg.zdiv, z2 = z - z1 * sg.zdiv;
-        const int nkt = (sg.kchunk ? max(0, min(sg.K, sg.ktotal - z2 * sg.kchunk)) : sg.K) / H3_BK;
-        if (nkt == 0) continue;      // (block-uniform) nothing to add from this segment
-        const unsigned char* gp[4];
-        long gstep;
         if (!stB) {
             const unsigned char* Ag = sg.A + (long)z1 * sg.strideA + (long)z2 * sg.strideA2;
             if constexpr (!A_TR) {
@@ -306,52 +302,36 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
                     gp[j] = Bg + (long)((wave & 3) * 4 + j) * sg.ldb + (ncol / 128) * 512 + ((lane >> 4) & 1) * 256 + (((lane & 15) ^ (j << 2)) << 4);
             }
         }
-        if (TWOSEG && s > 0) {
-            // scale domain change: acc holds sum / (sa0[m]*sb0[n]); continue in units of sa1[m]*sb1[n].
-            // Powers of two, so the rescale is exact.  (memory clobbers keep the loads from being
-            // hoisted into one 64-register burst)
-            const H3Seg& s0 = g.seg[0];
-            const int y1 = z / s0.zdiv, y2 = z - y1 * s0.zdiv;
-            const float* sa0 = s0.sa + (long)y1 * s0.strideSA + (long)y2 * s0.strideSA2;
-            const float* sb0 = s0.sb + (long)y1 * s0.strideSB + (long)y2 * s0.strideSB2;
-            const float* sa1 = sg.sa + (long)z1 * sg.strideSA + (long)z2 * sg.strideSA2;
-            const float* sb1 = sg.sb + (long)z1 * sg.strideSB + (long)z2 * sg.strideSB2;
-            float cf[2];
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn) {
-                const int c = PAIRED ? (tn == 0 ? n0 + wn * 32 + l31 : g.pair_off + n0 + wn * 32 + l31) : min(n0 + tn * 128 + wn * 32 + l31, g.N - 1);
-                cf[tn] = sb0[(long)c * s0.sb_mul] / sb1[(long)c * sg.sb_mul];
-            }
-            // row factors through LDS (the stage buffers are idle here): 256 floats, then 16 ds_read_b128 per lane
-            __syncthreads();
-            float* rfl = reinterpret_cast<float*>(lds);
+    };
+
+    const H3Seg& sg0 = g.seg[0];
+    const int zz2 = z % sg0.zdiv;
+    const int nkt0 = (sg0.kchunk ? max(0, min(sg0.K, sg0.ktotal - zz2 * sg0.kchunk)) : sg0.K) / H3_BK;
+    const int nkt = TWOSEG ? nkt0 + g.seg[1].K / H3_BK : nkt0;      // (TWOSEG: the host guarantees K0 >= 64, K1 >= 48, no kchunk)
+    if (nkt > 0) {
+        const unsigned char* gp[4];
+        long gstep;
+        setup(sg0, gp, gstep);
+        if constexpr (TWOSEG) {
+            // acc changes its scale domain between the segments (sum/(sa0[m]*sb0[n]) -> units of sa1[m]*sb1[n]; powers of
+            // two, exact).  The row factors wait in the 1 KiB of LDS behind the stage ring.
+            const H3Seg& s1 = g.seg[1];
+            const float* sa0 = sg0.sa + (long)(z / sg0.zdiv) * sg0.strideSA + (long)zz2 * sg0.strideSA2;
+            const float* sa1 = s1.sa + (long)(z / s1.zdiv) * s1.strideSA + (long)(z % s1.zdiv) * s1.strideSA2;
             if (tid < 256) {
                 const int m = min(m0 + tid, g.M - 1);
-                rfl[tid] = sa0[(long)m * s0.sa_mul] / sa1[(long)m * sg.sa_mul];
+                reinterpret_cast<float*>(lds + H3_LDS)[tid] = sa0[(long)m * sg0.sa_mul] / sa1[(long)m * s1.sa_mul];
             }
-            __syncthreads();
-#pragma unroll
-            for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 rf = *reinterpret_cast<const f32x4*>(rfl + wm * 128 + tm * 32 + 8 * j + 4 * h);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        acc[tm][0][4 * j + i] *= rf[i] * cf[0];
-                        acc[tm][1][4 * j + i] *= rf[i] * cf[1];
-                    }
-                }
-            __syncthreads();      // every wave is done with the stage buffers the next DMA overwrites
         }
 
         // ---- prologue: tiles 0..2 in flight, fragments of tile 0 in registers
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-            if (p < nkt) {
+            if (p < nkt0) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) h3_glds16(gp[j] + p * gstep, lds + p * H3_STAGE + sdst + j * 1024);
             }
-        if (nkt >= 3) H3_WAIT_VM(8); else if (nkt == 2) H3_WAIT_VM(4); else H3_WAIT_VM(0);
+        if (nkt0 >= 3) H3_WAIT_VM(8); else if (nkt0 == 2) H3_WAIT_VM(4); else H3_WAIT_VM(0);
         H3_BARRIER();
         f16x8 ah[4], al[4], bh[2], bl[2];
 #pragma unroll
@@ -368,15 +348,46 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
         // ---- stages.  At the top of stage t the wave's own pieces of tile t+1 must have landed
         // (tile t+2 may stay in flight: vmcnt(4)); the barrier then makes tile t+1 readable for
         // everyone and proves that buffer (t+3)&3 — read last during stage t-2 — is free.
-#define H3_RUN(FULLN, PH)                                                                                              \
-        {                                                                                                              \
-            int t = 0;                                                                                                 \
-            for (; t + 3 < nkt; ++t) {                                                                                 \
+        // TWOSEG: ONE pipeline over both segments — the DMA switches to the second segment's operands three
+        // stages before the MFMAs do, the accumulators are rescaled between stage nkt0-1 and stage nkt0.
+#define H3_STEADY(FULLN, PH, LIMIT, TILE0)                                                                             \
+            for (; t + 3 < (LIMIT); ++t) {                                                                             \
                 H3_WAIT_VM(4);                                                                                         \
                 if (VARIANT != 4) H3_BARRIER();                                                                        \
                 h3_stage<A_TR, B_TR, FULLN, VARIANT != 2 && VARIANT != 3, VARIANT != 1 && VARIANT != 3, PH>(           \
-                    acc, ah, al, bh, bl, lds + ((t + 1) & 3) * H3_STAGE, f, gp, (long)(t + 3) * gstep,                 \
+                    acc, ah, al, bh, bl, lds + ((t + 1) & 3) * H3_STAGE, f, gp, (long)(t + 3 - (TILE0)) * gstep,       \
                     lds + ((t + 3) & 3) * H3_STAGE + sdst);                                                            \
+            }
+#define H3_RUN(FULLN, PH)                                                                                              \
+        {                                                                                                              \
+            int t = 0;                                                                                                 \
+            if constexpr (TWOSEG) {                                                                                    \
+                H3_STEADY(FULLN, PH, nkt0, 0)                                                                          \
+                setup(g.seg[1], gp, gstep);                                                                            \
+                H3_STEADY(FULLN, PH, nkt0 + 3, nkt0)                                                                   \
+                {                                                                                                      \
+                    const H3Seg& s1 = g.seg[1];                                                                        \
+                    const float* sb0 = sg0.sb + (long)(z / sg0.zdiv) * sg0.strideSB + (long)zz2 * sg0.strideSB2;       \
+                    const float* sb1 = s1.sb + (long)(z / s1.zdiv) * s1.strideSB + (long)(z % s1.zdiv) * s1.strideSB2; \
+                    float cf[2];                                                                                       \
+                    _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) {                                                 \
+                        const int c = PAIRED ? (tn == 0 ? n0 + wn * 32 + l31 : g.pair_off + n0 + wn * 32 + l31)        \
+                                             : min(n0 + tn * 128 + wn * 32 + l31, g.N - 1);                            \
+                        cf[tn] = sb0[(long)c * sg0.sb_mul] / sb1[(long)c * s1.sb_mul];                                 \
+                    }                                                                                                  \
+                    const float* rfl = reinterpret_cast<const float*>(lds + H3_LDS);                                   \
+                    _Pragma("unroll") for (int tm = 0; tm < 4; ++tm)                                                   \
+                        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
+                            const f32x4 rf = *reinterpret_cast<const f32x4*>(rfl + wm * 128 + tm * 32 + 8 * j + 4 * h);\
+                            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+                                acc[tm][0][4 * j + i] *= rf[i] * cf[0];                                                \
+                                acc[tm][1][4 * j + i] *= rf[i] * cf[1];                                                \
+                            }                                                                                          \
+                        }                                                                                              \
+                }                                                                                                      \
+                H3_STEADY(FULLN, PH, nkt, nkt0)                                                                        \
+            } else {                                                                                                   \
+                H3_STEADY(FULLN, PH, nkt, 0)                                                                           \
             }                                                                                                          \
             for (; t + 1 < nkt; ++t) {                                                                                 \
                 if (t + 2 < nkt) H3_WAIT_VM(4); else H3_WAIT_VM(0);                                                    \
@@ -389,6 +400,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
         if (full_n) { if (stB) H3_RUN(true, 1) else H3_RUN(true, 0) }
         else { if (stB) H3_RUN(false, 1) else H3_RUN(false, 0) }
 #undef H3_RUN
+#undef H3_STEADY
     }
 
     // ---- epilogue: D col = l31, row = (r&3) + 8*(r>>2) + 4*h; scales of the LAST segment
@@ -401,26 +413,52 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
         const int c = n0 + wn * 32 + l31;
         const auto cc = epi.col(z, c);
         const float sc0 = sb[(long)c * sbm], sc1 = sb[(long)(g.pair_off + c) * sbm];
+        if constexpr (epi_has_aux<Epi>::value) {
+            // the epilogue's own loads (gate operands ...) are cold HBM reads: those of row block tm+1 are issued
+            // before the stores of row block tm, so that only the first block's latency is exposed
+            // (half row blocks of 8 accumulator registers: two sets of 8 rows fit beside the 128 accumulators)
+            decltype(epi.row(0, 0)) rw[2][8];
+            float sr[2][8];
+            decltype(epi.aux(0, 0, 0, rw[0][0])) ax[2][8];
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm) {
-            decltype(epi.row(0, 0)) rw[16];
-            float sr[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = min(m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, g.M - 1);
-                rw[r] = epi.row(z, m);
-                sr[r] = sa[(long)m * sam];
+            for (int r = 0; r < 8; ++r) {
+                const int m = min(m0 + wm * 128 + (r & 3) + 8 * (r >> 2) + 4 * h, g.M - 1);
+                rw[0][r] = epi.row(z, m);
+                sr[0][r] = sa[(long)m * sam];
+                ax[0][r] = epi.aux(z, m, c, rw[0][r]);
             }
-            if constexpr (epi_has_aux<Epi>::value) {
-                decltype(epi.aux(0, 0, 0, rw[0])) ax[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ax[r] = epi.aux(z, min(m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, g.M - 1), c, rw[r]);
+            for (int hb = 0; hb < 8; ++hb) {
+                if (hb < 7) {
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        const int r = ((hb + 1) & 1) * 8 + r8;
+                        const int m = min(m0 + wm * 128 + ((hb + 1) >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, g.M - 1);
+                        rw[(hb + 1) & 1][r8] = epi.row(z, m);
+                        sr[(hb + 1) & 1][r8] = sa[(long)m * sam];
+                        ax[(hb + 1) & 1][r8] = epi.aux(z, m, c, rw[(hb + 1) & 1][r8]);
+                    }
+                }
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int tm = hb >> 1, r = (hb & 1) * 8 + r8;
+                    const int m = m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m < g.M)
+                        epi.store2(z, m, c, acc[tm][0][r] * (sr[hb & 1][r8] * sc0), acc[tm][1][r] * (sr[hb & 1][r8] * sc1), rw[hb & 1][r8], cc,
+                                   ax[hb & 1][r8]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) {
+                decltype(epi.row(0, 0)) rw[16];
+                float sr[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (m < g.M) epi.store2(z, m, c, acc[tm][0][r] * (sr[r] * sc0), acc[tm][1][r] * (sr[r] * sc1), rw[r], cc, ax[r]);
+                    const int m = min(m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, g.M - 1);
+                    rw[r] = epi.row(z, m);
+                    sr[r] = sa[(long)m * sam];
                 }
-            } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -470,7 +508,8 @@ template <bool A_TR, bool B_TR, bool PAIRED, bool TWOSEG, class Epi, int VARIANT
 inline hipError_t launch_gemm_h3x(H3Args g, int batches, Epi epi, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_kernel<A_TR, B_TR, PAIRED, TWOSEG, Epi, VARIANT>), hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_kernel<A_TR, B_TR, PAIRED, TWOSEG, Epi, VARIANT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            H3_LDS + (TWOSEG ? 1024 : 0));
         attr_set = true;
     }
     g.tiles_m = (g.M + H3_BM - 1) / H3_BM;
@@ -492,7 +531,8 @@ inline hipError_t launch_gemm_h3x(H3Args g, int batches, Epi epi, hipStream_t st
         g.mp = 0; g.gw = 1;
         grid = dim3(8 * ((batches + 7) / 8) * g.tiles_m * g.tiles_n, 1, 1);
     }
-    hipLaunchKernelGGL((gemm_h3_kernel<A_TR, B_TR, PAIRED, TWOSEG, Epi, VARIANT>), grid, dim3(H3_THREADS), H3_LDS, st, g, epi);
+    if (TWOSEG && (g.seg[0].K < 64 || g.seg[1].K < 48 || g.seg[0].kchunk || g.seg[1].kchunk)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((gemm_h3_kernel<A_TR, B_TR, PAIRED, TWOSEG, Epi, VARIANT>), grid, dim3(H3_THREADS), H3_LDS + (TWOSEG ? 1024 : 0), st, g, epi);
     return hipGetLastError();
 }
 

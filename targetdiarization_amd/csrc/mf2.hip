@@ -114,6 +114,10 @@ struct EpiBias { const float* b; float* out; long ld;   // b may be null
     __device__ float col(int, int n) const { return b ? b[n] : 0.f; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
     __device__ void store(int, int m, int n, float v, EpiNone, float c) const { out[(long)m * ld + n] = v + c; } };
+struct EpiBiasHalves { const float* b; float* out; long M;   // [M][2C] written as [2][M][C] (the two mask branches)
+    __device__ float col(int, int n) const { return b[n]; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { out[(long)(n >> 9) * M * C + (long)m * C + (n & 511)] = v + c; } };
 struct EpiBiasResidual { const float* b; float* x; long ld;   // x += acc + b   mossformer_block.py:424-425
     __device__ float col(int, int n) const { return b[n]; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
@@ -218,7 +222,7 @@ struct tdx_mf2 {
     size_t n_weights;
     unsigned char* dev_planes;      // split-f16 planes + scales of every nn.Linear weight
     float* dev_static;              // [L][2] inverse static scales
-    H3W hWenc, hWout;
+    H3W hWenc, hWout, hWtg, hWdec1;
     std::vector<LayerW> layers;
     const float *encT, *gn1g, *gn1b, *Wenc, *pe_scale, *inv_freq, *rot_freqs, *lnfg, *lnfb, *gn2g, *gn2b, *prelu, *Wout, *bout,
         *Wtg, *btg, *Wdec1, *decT;
@@ -267,7 +271,7 @@ bool make_plan(const tdx_mf2* h, int B, int T, Plan& P) {
     P.o = take(M * 1024); P.t = take(M * C);
     P.hraw = take(M * INNER); P.h = take(M * INNER);
     P.hp = take(M * 1024);      // split-f16 planes of the current GEMM's A operand (<= 1024 channels: 4 KB per row)
-    P.hs = take(M);             // and its row scales
+    P.hs = take(2 * M);         // and its row scales (2M rows of 512 in the output head)
     // attention on the x3 core: K-major planes of v|u (pad rows zero), row-major planes + row scales of the
     // relu^2 similarity, row scales of quad_q / lin_q / quad_k (their planes live in the qk4 slots), K-major
     // planes of Kvu with one scale per sample (+ its atomicMax word)
@@ -276,7 +280,7 @@ bool make_plan(const tdx_mf2* h, int B, int T, Plan& P) {
     P.Asc = take((size_t)B * P.Sp);
     P.qks = take((size_t)3 * B * P.Sp);
     P.KvuP = take((size_t)B * QK * HID);
-    P.kvus = take((size_t)2 * B + 64);
+    P.kvus = take((size_t)B + (size_t)B * (QK * HID / 1024) + 64);
     P.uvpre = take(M * C); P.uv = take(M * C); P.f = take(M * INNER); P.p = take(M * INNER);
     P.c1 = take(M * INNER); P.c2 = take(M * INNER);
     P.pe = take((size_t)P.S * C); P.rc = take((size_t)P.S * 16); P.rsn = take((size_t)P.S * 16);
@@ -386,11 +390,11 @@ int attention_core_h3(const unsigned char* qkP, const float* qks, const unsigned
         EpiStore e{slab, (long)QK, (long)QK * 2 * E};
         if (tdx::launch_gemm_h3x<true, true, false, false>(g, B * splits, e, st_) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
         const long per = (long)QK * 2 * E;
-        unsigned* mx = reinterpret_cast<unsigned*>(kvus + B);
-        if (hipMemsetAsync(mx, 0, (size_t)B * sizeof(unsigned), st_) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
-        hipLaunchKernelGGL(kvu_reduce_t_kernel, dim3((unsigned)((per / 4 + 255) / 256), B), dim3(256), 0, st_, slab, kvu, splits, per, (float)S, mx);
+        const int nb = (int)((per / 4 + 255) / 256);
+        float* bmax = kvus + B;          // [B][nb] block maxima
+        hipLaunchKernelGGL(kvu_reduce_t_kernel, dim3(nb, B), dim3(256), 0, st_, slab, kvu, splits, per, (float)S, bmax);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(kvu_planes_kernel, dim3((unsigned)((128 * (2 * E / 8) + 255) / 256), B), dim3(256), 0, st_, kvu, mx, KvuP, kvus, 2 * E);
+        hipLaunchKernelGGL(kvu_planes_kernel, dim3((unsigned)((128 * (2 * E / 8) + 255) / 256), B), dim3(256), 0, st_, kvu, bmax, nb, KvuP, kvus, 2 * E);
         LAUNCH_CHECK();
     }
     {   // [A | lin_q] x [VU ; Kvu] with the gate epilogue                                mossformer_block.py:269-294, :217
@@ -684,6 +688,7 @@ int tdx_mf2_create(const tdx_mf2_config* cfg, const void* blob, size_t blob_byte
             jobs.push_back({w.Wp, INNER, INNER, &w.hWp}); jobs.push_back({w.W2, C, INNER, &w.hW2});
         }
         jobs.push_back({h->Wenc, C, C, &h->hWenc}); jobs.push_back({h->Wout, 2 * C, C, &h->hWout});
+        jobs.push_back({h->Wtg, 2 * C, C, &h->hWtg}); jobs.push_back({h->Wdec1, C, C, &h->hWdec1});
         size_t bytes = 0;
         for (const Job& j : jobs) bytes += (size_t)j.N * j.K * 4 + (size_t)al(j.N) * 4;
         e = hipMalloc(&h->dev_planes, bytes);
@@ -868,20 +873,26 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
     hipLaunchKernelGGL((gn_apply_kernel<1>), dim3((unsigned)((M * 128 + 255) / 256)), dim3(256), 0, st, t, gnstat, h->gn2g, h->gn2b, z,
                        h->prelu, r, M, S);
     LAUNCH_CHECK();
-    float* r2 = o;       // [M,1024]
-    TRY(split_linear_h3(r, C, hp, hs, (int)M, h->hWout, 2 * C, C, EpiBias{h->bout, r2, 2 * C}, st));
+    float* r2 = o;       // [2][M][512]: the conv1d_out rows of the two speakers
+    TRY(split_linear_h3(r, C, hp, hs, (int)M, h->hWout, 2 * C, C, EpiBiasHalves{h->bout, r2, M}, st));
     float* gate = vu;    // [2][M][512]
     {
-        GemmArgs g = make_args((int)M, C, make_seg(r2, 2 * C, h->Wtg, C, C, C, 0));
-        g.pair_off = C;
-        EpiTanhSig e{h->btg, gate, M * C};
-        if (launch_gemm<false, false, true, false>(g, 2, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+        if (tdx::launch_h3_split_rows(r2, C, hp, hs, 2 * M, C, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+        tdx::H3Args g{};
+        g.seg[0] = tdx::h3_seg(hp, hs, 4L * C, h->hWtg.p, h->hWtg.s, 4L * C, C);
+        g.seg[0].strideA = M * 4L * C; g.seg[0].strideSA = M;
+        g.nseg = 1; g.M = (int)M; g.N = C; g.pair_off = C;
+        if (tdx::launch_gemm_h3<true>(g, 2, EpiTanhSig{h->btg, gate, M * C}, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
     }
     float* EM = hid;     // [2][M][512]
     {
-        GemmArgs g = make_args((int)M, C, make_seg(gate, C, h->Wdec1, C, C, M * C, 0));
+        if (tdx::launch_h3_split_rows(gate, C, hp, hs, 2 * M, C, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+        tdx::H3Args g{};
+        g.seg[0] = tdx::h3_seg(hp, hs, 4L * C, h->hWdec1.p, h->hWdec1.s, 4L * C, C);
+        g.seg[0].strideA = M * 4L * C; g.seg[0].strideSA = M;
+        g.nseg = 1; g.M = (int)M; g.N = C;
         EpiMaskMul e{E, EM, h->taps ? ws + P.mask : nullptr, M * C};
-        if (launch_gemm<false, false, false, false>(g, 2, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+        if (tdx::launch_gemm_h3<false>(g, 2, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
     }
     float* D = t;        // [2][M][16]
     hipLaunchKernelGGL(decoder_dot_kernel, rows4(2 * M), dim3(256), 0, st, EM, h->decT, D, 2 * M);
@@ -928,7 +939,7 @@ static void attn_plan(int B, int S, int E, int& splits, int& kchunk, size_t& qk4
     slab = take((size_t)B * splits * QK * 2 * E); kvu = take((size_t)B * QK * 2 * E);
     if (E % 128 == 0) {   // split-f16 x3 path (as the model): planes of the heads, of v|u, of the similarity and of Kvu, and scales
         take((size_t)4 * B * Sp * QK); take((size_t)B * Sp * 2 * E); take((size_t)B * G * 65536); take((size_t)B * QK * 2 * E);
-        take((size_t)4 * B * Sp); take((size_t)2 * B + 64); take(64);
+        take((size_t)4 * B * Sp); take((size_t)B + (size_t)B * (QK * 2 * E / 1024) + 64); take(64);
     }
     total = off;
 }
@@ -969,7 +980,7 @@ int tdx_cal_attention(const float* quad_q, const float* lin_q, const float* quad
     unsigned char* AbufP = (unsigned char*)p; p += al((size_t)B * G * 65536);
     unsigned char* KvuP = (unsigned char*)p; p += al((size_t)B * QK * 2 * E);
     float* qks = p; p += al((size_t)4 * B * Sp);
-    float* kvus = p; p += al((size_t)2 * B + 64);
+    float* kvus = p; p += al((size_t)B + (size_t)B * (QK * 2 * E / 1024) + 64);
     float* stt = p;                       // [0..1] inverse scales of v|u, lin_k ; [2..3] their maxima (bits)
     float* Asc = qks + 3L * B * Sp;
     unsigned* mx = reinterpret_cast<unsigned*>(stt + 2);

@@ -272,32 +272,44 @@ __global__ __launch_bounds__(256) void ddn_conv2_kernel(const float* __restrict_
         g0 = in_g[ic]; be0 = in_b[ic]; al0 = prelu[ic];
         g1 = in_g[ic + 1]; be1 = in_b[ic + 1]; al1 = prelu[ic + 1];
     }
-    float w0[K], w1[K];
+    // the two input channels of an output ride in the two halves of v_pk_fma_f32 (39 packed FMAs per output
+    // instead of 78 scalar ones); their partial sums are added at the end
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f w[K];
 #pragma unroll
-    for (int t = 0; t < K; ++t) { w0[t] = w2T[(t * 2 + 0) * 256 + j]; w1[t] = w2T[(t * 2 + 1) * 256 + j]; }
-    auto ld = [&](int s) -> float2 {
-        if (s < 0 || s >= S) return make_float2(0.f, 0.f);
-        float2 v = *reinterpret_cast<const float2*>(src + (long)s * 256);
+    for (int t = 0; t < K; ++t) { w[t].x = w2T[(t * 2 + 0) * 256 + j]; w[t].y = w2T[(t * 2 + 1) * 256 + j]; }
+    auto ld = [&](int s) -> v2f {
+        v2f v = {0.f, 0.f};
+        if (s < 0 || s >= S) return v;
+        v = *reinterpret_cast<const v2f*>(src + (long)s * 256);
         if (from_c1) {
             v.x = (v.x - mu0) * rs0 * g0 + be0; v.x = v.x >= 0.f ? v.x : al0 * v.x;
             v.y = (v.y - mu1) * rs1 * g1 + be1; v.y = v.y >= 0.f ? v.y : al1 * v.y;
         }
         return v;
     };
-    float2 win[W];
+    v2f win[W];
 #pragma unroll
     for (int i = 0; i < K - 1; ++i) win[i] = ld(s_begin - 38 + 2 * i);
+    // the U new window entries of iteration i0 are loaded one iteration ahead (nx): their latency hides behind
+    // the 4 x 39 packed FMAs of the previous iteration instead of stalling each one
+    v2f nx[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) nx[i] = ld(s_begin + 2 * i + 38);
     double sum = 0.0, sq = 0.0;
     for (int i0 = 0; i0 < DDN_TS; i0 += U) {
         if (s_begin + 2 * i0 >= S) break;
 #pragma unroll
-        for (int i = 0; i < U; ++i) win[K - 1 + i] = ld(s_begin + 2 * (i0 + i) + 38);
+        for (int i = 0; i < U; ++i) win[K - 1 + i] = nx[i];
+#pragma unroll
+        for (int i = 0; i < U; ++i) nx[i] = ld(s_begin + 2 * (i0 + U + i) + 38);
         float ps = 0.f, pq = 0.f;
 #pragma unroll
         for (int i = 0; i < U; ++i) {
-            float o = 0.f;
+            v2f o2 = {0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < K; ++t) { o = fmaf(w0[t], win[i + t].x, o); o = fmaf(w1[t], win[i + t].y, o); }
+            for (int t = 0; t < K; ++t) o2 = __builtin_elementwise_fma(w[t], win[i + t], o2);
+            const float o = o2.x + o2.y;
             const int s = s_begin + 2 * (i0 + i);
             if (s < S) {
                 c2[((long)b * S + s) * 256 + j] = o;
@@ -373,11 +385,13 @@ __global__ __launch_bounds__(256) void fsmn_tail_kernel(const float* __restrict_
     if (lane == 0) hs[m] = inv;
 }
 
-// x3 path: kvuT[b][ch][d] = (sum_sp slab[b][sp][ch][d]) / S in fp32, and max |kvuT[b]| as float bits (atomicMax;
-// mx must be zeroed before).  Then kvu_planes_kernel re-writes it as K-major planes KvuP[b][d][16][2][128]
-// with one exact power-of-two scale per sample (the B operand of the attention GEMM's linear segment).
+// x3 path: kvuT[b][ch][d] = (sum_sp slab[b][sp][ch][d]) / S in fp32, and per block the max |value| (bmax[b][block];
+// no atomics: 1024 waves hammering one word cost 250 us).  Then kvu_planes_kernel reduces the block maxima and
+// re-writes kvuT as K-major planes KvuP[b][d][16][2][128] with one exact power-of-two scale per sample (the B
+// operand of the attention GEMM's linear segment).
 __global__ __launch_bounds__(256) void kvu_reduce_t_kernel(const float* __restrict__ slab, float* __restrict__ kvu, int splits, long per,
-                                                            float S, unsigned* __restrict__ mx) {
+                                                            float S, float* __restrict__ bmax) {
+    __shared__ float wmax[4];
     const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
     float m = 0.f;
@@ -393,18 +407,27 @@ __global__ __launch_bounds__(256) void kvu_reduce_t_kernel(const float* __restri
         m = h3_absmax4(acc);
     }
     m = h3_wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax(mx + b, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) bmax[(long)b * gridDim.x + blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
 }
-__global__ __launch_bounds__(256) void kvu_planes_kernel(const float* __restrict__ kvu, const unsigned* __restrict__ mx,
+__global__ __launch_bounds__(256) void kvu_planes_kernel(const float* __restrict__ kvu, const float* __restrict__ bmax, int nbmax,
                                                           unsigned char* __restrict__ planes, float* __restrict__ scale, int E2) {
     // thread = (d, 8 consecutive ch); kvu[b] is [E2 ch][128 d]
+    __shared__ float wmax[4];
     const int b = blockIdx.y;
+    float mu = 0.f;
+    for (int i = threadIdx.x; i < nbmax; i += 256) mu = fmaxf(mu, bmax[(long)b * nbmax + i]);
+    mu = h3_wave_max(mu);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mu;
+    __syncthreads();
+    mu = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int per = E2 / 8;
     if (i >= 128 * per) return;
     const int d = i / per, ch = (i - d * per) * 8;
     float inv;
-    const float s = h3_row_scale(__uint_as_float(mx[b]), inv);
+    const float s = h3_row_scale(mu, inv);
     const float* src = kvu + (long)b * E2 * 128 + (long)ch * 128 + d;
     f16x8 hi, lo;
 #pragma unroll

@@ -208,20 +208,36 @@ __global__ __launch_bounds__(256) void ddn_conv1_kernel(const float* __restrict_
     float w[K];
 #pragma unroll
     for (int t = 0; t < K; ++t) w[t] = w1T[t * 256 + ch];
-    auto ld = [&](int s) -> float { return (s >= 0 && s < S) ? in[(long)s * 256] : 0.f; };
+    // unconditional loads from clamped addresses, masked afterwards, one iteration ahead (see ddn_conv2_kernel)
+    auto ldraw = [&](int s) -> float { return in[(long)min(max(s, 0), S - 1) * 256]; };
+    auto fix = [&](float v, int s) -> float { return (s >= 0 && s < S) ? v : 0.f; };
     float win[W];
 #pragma unroll
-    for (int i = 0; i < K - 1; ++i) win[i] = ld(s_begin - 19 + i);
+    for (int i = 0; i < K - 1; ++i) win[i] = ldraw(s_begin - 19 + i);
+#pragma unroll
+    for (int i = 0; i < K - 1; ++i) win[i] = fix(win[i], s_begin - 19 + i);
+    float nx[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) nx[i] = ldraw(s_begin + 19 + i);
     double sum = 0.0, sq = 0.0;
     for (int s0 = s_begin; s0 < s_end; s0 += U) {
 #pragma unroll
-        for (int i = 0; i < U; ++i) win[K - 1 + i] = ld(s0 + 19 + i);
+        for (int i = 0; i < U; ++i) win[K - 1 + i] = fix(nx[i], s0 + 19 + i);
+#pragma unroll
+        for (int i = 0; i < U; ++i) nx[i] = ldraw(s0 + U + 19 + i);
         float ps = 0.f, pq = 0.f;
+        float ov[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) ov[i] = 0.f;
+#pragma unroll
+        for (int t = 0; t < K; ++t)
+#pragma unroll
+            for (int i = 0; i < U; ++i) ov[i] = fmaf(w[t], win[i + t], ov[i]);
+#pragma unroll
+        for (int i = 0; i < U; ++i) asm volatile("" : "+v"(ov[i]));
 #pragma unroll
         for (int i = 0; i < U; ++i) {
-            float o = 0.f;
-#pragma unroll
-            for (int t = 0; t < K; ++t) o = fmaf(w[t], win[i + t], o);
+            const float o = ov[i];
             if (s0 + i < s_end) {
                 c1[((long)b * S + s0 + i) * 256 + ch] = o;
                 ps += o; pq = fmaf(o, o, pq);
@@ -278,38 +294,53 @@ __global__ __launch_bounds__(256) void ddn_conv2_kernel(const float* __restrict_
     v2f w[K];
 #pragma unroll
     for (int t = 0; t < K; ++t) { w[t].x = w2T[(t * 2 + 0) * 256 + j]; w[t].y = w2T[(t * 2 + 1) * 256 + j]; }
-    auto ld = [&](int s) -> v2f {
-        v2f v = {0.f, 0.f};
-        if (s < 0 || s >= S) return v;
-        v = *reinterpret_cast<const v2f*>(src + (long)s * 256);
+    // loads are unconditional from a clamped (always valid) address and their fix-up (InstanceNorm + PReLU of the
+    // c1 half, zero outside [0, S)) is applied when the value enters the window: a conditional load compiles to a
+    // branch with a full vmcnt(0) wait per element, which serialises the whole kernel on memory latency
+    auto ldraw = [&](int s) -> v2f { return *reinterpret_cast<const v2f*>(src + (long)min(max(s, 0), S - 1) * 256); };
+    auto fix = [&](v2f v, int s) -> v2f {
         if (from_c1) {
             v.x = (v.x - mu0) * rs0 * g0 + be0; v.x = v.x >= 0.f ? v.x : al0 * v.x;
             v.y = (v.y - mu1) * rs1 * g1 + be1; v.y = v.y >= 0.f ? v.y : al1 * v.y;
         }
+        const bool ok = s >= 0 && s < S;
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f;
         return v;
     };
     v2f win[W];
 #pragma unroll
-    for (int i = 0; i < K - 1; ++i) win[i] = ld(s_begin - 38 + 2 * i);
+    for (int i = 0; i < K - 1; ++i) win[i] = ldraw(s_begin - 38 + 2 * i);
+#pragma unroll
+    for (int i = 0; i < K - 1; ++i) win[i] = fix(win[i], s_begin - 38 + 2 * i);
     // the U new window entries of iteration i0 are loaded one iteration ahead (nx): their latency hides behind
-    // the 4 x 39 packed FMAs of the previous iteration instead of stalling each one
+    // the 4 x 39 packed FMAs of the previous iteration
     v2f nx[U];
 #pragma unroll
-    for (int i = 0; i < U; ++i) nx[i] = ld(s_begin + 2 * i + 38);
+    for (int i = 0; i < U; ++i) nx[i] = ldraw(s_begin + 2 * i + 38);
     double sum = 0.0, sq = 0.0;
     for (int i0 = 0; i0 < DDN_TS; i0 += U) {
         if (s_begin + 2 * i0 >= S) break;
 #pragma unroll
-        for (int i = 0; i < U; ++i) win[K - 1 + i] = nx[i];
+        for (int i = 0; i < U; ++i) win[K - 1 + i] = fix(nx[i], s_begin + 2 * (i0 + i) + 38);
 #pragma unroll
-        for (int i = 0; i < U; ++i) nx[i] = ld(s_begin + 2 * (i0 + U + i) + 38);
+        for (int i = 0; i < U; ++i) nx[i] = ldraw(s_begin + 2 * (i0 + U + i) + 38);
         float ps = 0.f, pq = 0.f;
+        // the U accumulation chains are interleaved tap by tap: a packed FMA that depends on the previous one
+        // costs wait states (the compiler pads a single chain with s_nop)
+        v2f o2[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) o2[i] = v2f{0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < K; ++t)
+#pragma unroll
+            for (int i = 0; i < U; ++i) o2[i] = __builtin_elementwise_fma(w[t], win[i + t], o2[i]);
+        // (keeps the compiler from sinking each chain into the conditional store of its output, which would
+        // serialise the chains again)
+#pragma unroll
+        for (int i = 0; i < U; ++i) asm volatile("" : "+v"(o2[i]));
 #pragma unroll
         for (int i = 0; i < U; ++i) {
-            v2f o2 = {0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < K; ++t) o2 = __builtin_elementwise_fma(w[t], win[i + t], o2);
-            const float o = o2.x + o2.y;
+            const float o = o2[i].x + o2[i].y;
             const int s = s_begin + 2 * (i0 + i);
             if (s < S) {
                 c2[((long)b * S + s) * 256 + j] = o;

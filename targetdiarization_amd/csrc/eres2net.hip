@@ -159,6 +159,7 @@ int conv_gemm(const float* A, long lda, const float* dev, const ConvW& cw, int B
               Epi e, hipStream_t st) {
     const long M = (long)B * Hout * Wout;
     GemmArgs g = make_args((int)M, cw.Npad, make_seg(A, lda, dev + cw.w, (long)cw.taps * cw.cinp, cw.cinp));
+    g.n_valid = up(cw.N, 32);
     g.cv_Hin = Hin; g.cv_Win = Win; g.cv_Hout = Hout; g.cv_Wout = Wout; g.cv_stride = stride; g.cv_ntaps = cw.taps; g.cv_cin = cw.cinp;
     if (launch_gemm<false, false, false, false, Epi, 0, true>(g, 1, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
     return TDX_OK;

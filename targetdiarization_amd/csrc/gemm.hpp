@@ -68,6 +68,7 @@ struct GemmArgs {
     // reads input row (b, h*stride+dy, w*stride+dx) of A = [B*Hin*Win, lda] (zero outside), with
     // (dy,dx) = (tap/3-1, tap%3-1) for 9 taps or (0,0) for 1; weights B = [N][ntaps*cin].
     int cv_Hin, cv_Win, cv_Hout, cv_Wout, cv_stride, cv_ntaps, cv_cin;
+    int n_valid;      // fp32 core, !PAIRED: columns >= n_valid are never stored by the epilogue -> their MFMA tiles are skipped
     int pair_off;     // PAIRED: column offset of the second member of a pair
     int shift_k;      // SHIFT: k < shift_k is read from row m-1 (zero when m % shift_S == 0)
     int shift_S;
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, E
 #undef TDX_CV_DECODE
     }
     const int nseg = CONV ? g.cv_ntaps : g.nseg;
+    const bool nv0 = PAIRED || n0 + wn * 32 < g.n_valid, nv1 = PAIRED || n0 + 64 + wn * 32 < g.n_valid;
 
     for (int s = 0; s < nseg; ++s) {
         const bool s0 = CONV ? true : s == 0;
@@ -309,12 +311,21 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, E
                         b1[j] = Bs[(kc * 8 + h * 4 + j) * BN + nl1];
                     }
                 }
+                // column tiles beyond N (narrow convolutions: N = 32 / 64 / 96 of the 128-wide tile) are skipped
+                // (wave-uniform): their results are never stored
+                if (nv0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc00, 0, 0, 0);
-                    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc01, 0, 0, 0);
-                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc10, 0, 0, 0);
-                    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc11, 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) {
+                        acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc00, 0, 0, 0);
+                        acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc10, 0, 0, 0);
+                    }
+                }
+                if (nv1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc01, 0, 0, 0);
+                        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc11, 0, 0, 0);
+                    }
                 }
                 if (VARIANT != 3 && more) {
                     const int ktn = VARIANT == 4 ? (kt & 1) : kt + 1;     // 4: re-read k-tiles 0/1 (L1/L2-hot) — timing only
@@ -433,7 +444,7 @@ inline GemmSeg make_seg(const float* A, long lda, const float* B, long ldb, int 
 
 inline GemmArgs make_args(int M, int N, GemmSeg s0) {
     GemmArgs g{};
-    g.seg[0] = s0; g.seg[1] = s0; g.nseg = 1; g.M = M; g.N = N;
+    g.seg[0] = s0; g.seg[1] = s0; g.nseg = 1; g.M = M; g.N = N; g.n_valid = N;
     g.pair_off = 0; g.shift_k = 0; g.shift_S = 1;
     return g;
 }

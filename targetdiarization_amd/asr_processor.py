@@ -1,0 +1,85 @@
+"""ASRProcessor — the paraformer branch of the reference's `asr_detection` (ASRProcessor.py:373-442)
+around the MI355X encoder.  The swap point is `self.asr['paraformer'].generate(input=wav, hotword=…)`
+(:424): here the neural forward up to the encoder output runs through `tdx_pfenc_*`; everything
+after it (CIF predictor, NAR decoder, tokenizer, punctuation: third-party funasr) is a
+`decoder(encoder_out[T',512]) -> {"text": str, "timestamp": [[start_ms, end_ms], ...]}` plug-in.
+The post-processing of the result dicts (:427-437: ms -> s, token/timestamp pairing) and the
+print-and-degrade behaviour for missing engines (:375-389) are the reference's."""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import numpy as np
+
+
+class ASRProcessor:
+    def __init__(self, is_asr: bool = False, fast_asr: bool = False, asr_model_dir=None, is_vad: bool = False, vad_model_dir: str = "",
+                 is_punc: bool = False, punc_model_dir: str = "", is_timestamp: bool = False, timestamp_model_dir: str = "",
+                 is_emotion: bool = False, emotion_model_dir: str = "", is_diarization: bool = False, diarization_model_dir: str = "",
+                 is_asr_api: bool = False, api_config_path: str = "", verbose_log: bool = True, cuda_device: int = 0, ap=None,
+                 *, asr_state_dict=None, decoder: Optional[Callable] = None, punctuation: Optional[Callable] = None):
+        self.is_asr = is_asr
+        self.verbose_log = verbose_log
+        self.decoder = decoder
+        self.punctuation = punctuation
+        self.asr = {}
+        if is_asr and asr_state_dict is not None:
+            try:
+                from .paraformer import ParaformerEncoder
+                self.asr["paraformer"] = ParaformerEncoder(asr_state_dict, device=f"cuda:{cuda_device}")
+            except Exception as e:                       # ASRProcessor.py:215-264: print, feature off
+                print(f"Load ASR model failed: {e}")
+                self.is_asr = False
+
+    def punctuation_restore(self, text: str) -> str:
+        return self.punctuation(text) if self.punctuation is not None else text
+
+    @staticmethod
+    def detect_language(text: str) -> str:
+        """ASRProcessor.py:1013-1031: "en" only if Latin letters outnumber CJK ideographs, else "zh" """
+        chinese_count = sum(1 for ch in text if "\u4e00" <= ch <= "\u9fff")
+        english_count = sum(1 for ch in text if "a" <= ch.lower() <= "z")
+        return "en" if english_count > chinese_count else "zh"
+
+    @staticmethod
+    def paraformer_postprocess(result_list: list, no_punc: bool, punctuation_restore, detect_language) -> list:
+        """ASRProcessor.py:427-440 verbatim in meaning: timestamps ms -> s (3 decimals), paired with the
+        space-separated tokens (padded with "" when there are fewer tokens than stamps)."""
+        for i, result in enumerate(result_list):
+            if "timestamp" in result:
+                texts = result["text"].split(" ")
+                value = [[round(point / 1000, 3) for point in clip] for clip in result["timestamp"]]
+                if len(texts) < len(value):
+                    texts.extend([""] * (len(value) - len(texts)))
+                result_list[i]["timestamp"] = [(texts[j], value[j]) for j in range(len(value))]
+                if not no_punc:
+                    result_list[i]["text"] = punctuation_restore(result_list[i]["text"])
+            if "language" not in result:
+                result_list[i]["language"] = detect_language(result["text"])
+        return result_list
+
+    def asr_detection(self, wav_file, language: str = "auto", prompt: str = "", asr_engine: str = "paraformer", no_punc: bool = False,
+                      output_text_only: bool = False, output_raw_result: bool = False):
+        result_list = []
+        if not self.is_asr or not self.asr or self.decoder is None:
+            print("ASR models haven't been loaded. Return empty result.")
+            return "" if output_text_only else result_list
+        if asr_engine.lower() != "paraformer":
+            asr_engine = list(self.asr.keys())[0]
+        if isinstance(wav_file, (str, bytes)):
+            raise ValueError("asr_detection: pass 16 kHz float32 numpy audio (file decoding is outside the MI355X hot path)")
+        import torch
+        wavs = wav_file if isinstance(wav_file, list) else [wav_file]
+        enc = self.asr["paraformer"]
+        for k, w in enumerate(wavs):
+            x = torch.from_numpy(np.ascontiguousarray(np.asarray(w, dtype=np.float32).reshape(1, -1)))
+            out = enc(x.to(enc.device))[0]
+            res = dict(self.decoder(out))
+            res.setdefault("key", f"clip_{k}")
+            result_list.append(res)
+        if output_raw_result:
+            return result_list
+        result_list = self.paraformer_postprocess(result_list, no_punc, self.punctuation_restore, self.detect_language)
+        if output_text_only:
+            return "".join(r["text"] for r in result_list)
+        return result_list

@@ -59,3 +59,27 @@ def test_infer_single_and_no_target(gold, sd2):
     assert spk == "" and aud is None and len(res) == 1 and res[0]["speaker"] == "0" and res[0]["score"] == -1.0
     spk2, res2, aud2 = td.infer(mix, None)        # no target file: longest speaker becomes the target
     assert spk2 == "0" and aud2 is not None
+
+
+def test_target_asr_and_asr_processor_mirrors(gold):
+    """the reference-named host classes route through the same C-ABI paths"""
+    from targetdiarization_amd.asr_processor import ASRProcessor
+    from targetdiarization_amd.target_asr import TargetASR
+    from targetdiarization_amd.weights import recipe_eres2netv2_state_dict, recipe_paraformer_state_dict
+    tgt = _load(gold, "female_a.wav")
+    t = TargetASR(cuda_device=0, spk_state_dict=recipe_eres2netv2_state_dict(0))
+    e1 = t.get_speaker_embedding(tgt)
+    e2 = t.get_speaker_embeddings([tgt, tgt[:16000]])
+    assert e1.shape == (192,) and e1.dtype == np.float32 and np.allclose(e1, e2[0], rtol=1e-5, atol=1e-6)
+    assert 0.0 <= t.cosine_similarity(e1, e2[1]) <= 1.0 and abs(t.cosine_similarity(e1, e1) - 1.0) < 1e-6
+    seen = {}
+
+    def decoder(enc):
+        seen["shape"] = tuple(enc.shape)
+        return {"text": "a b", "timestamp": [[0, 500], [500, 900]]}
+    ap = ASRProcessor(is_asr=True, cuda_device=0, asr_state_dict=recipe_paraformer_state_dict(0, 2), decoder=decoder)
+    res = ap.asr_detection(tgt, asr_engine="paraformer", no_punc=True)
+    frames = 1 + (len(tgt) - 400) // 160
+    assert seen["shape"] == ((frames + 5) // 6, 512)
+    assert res[0]["timestamp"] == [("a", [0.0, 0.5]), ("b", [0.5, 0.9])] and res[0]["language"] == "en" and res[0]["key"] == "clip_0"
+    assert ap.asr_detection(tgt, output_text_only=True) == "a b"

@@ -148,6 +148,36 @@ def test_ragged_T_and_batch_vs_oracle(sd2, dev):
         assert e < REL_TOL, (B, T, e)
 
 
+def test_signal_statistics_vs_oracle(sd2, dev):
+    """Inputs far from the recipe noise: the split-f16 planes of v|u and lin_k use STATIC per-layer scales
+    (bounds from the weights), so silence, DC, clipping, impulses and a 60 dB level change must neither
+    overflow f16 nor lose accuracy against the fp64 oracle."""
+    from oracle import mossformer2_oracle as orc
+    from targetdiarization_amd.separator import MossFormer2Separator
+    sep = MossFormer2Separator(sd2, device=dev)
+    sd64 = orc.cast_state_dict(sd2, torch.float64)
+    T = 4104
+    t = torch.arange(T, dtype=torch.float32)
+    g = torch.Generator().manual_seed(5)
+    cases = {
+        "silence": torch.zeros(T),
+        "dc": torch.ones(T),
+        "square_clipped": torch.sign(torch.sin(2 * np.pi * 220.0 * t / 16000.0)),
+        "impulses": (torch.rand(T, generator=g) > 0.995).float() * 2 - (torch.rand(T, generator=g) > 0.995).float(),
+        "quiet_noise": torch.randn(T, generator=g) * 1e-4,
+        "loud_noise": torch.randn(T, generator=g).clamp(-1, 1),
+        "step_60dB": torch.cat([torch.randn(T // 2, generator=g) * 1e-3, torch.randn(T - T // 2, generator=g)]),
+    }
+    x = torch.stack(list(cases.values()))
+    ref = orc.mossformer2_forward(x.double(), sd64)
+    out = sep(x.to(dev))
+    assert torch.isfinite(out).all()
+    for i, name in enumerate(cases):
+        den = float(ref[i].norm())
+        err = float((out[i].double().cpu() - ref[i]).norm())
+        assert err <= REL_TOL * max(den, 1e-6), (name, err, den)
+
+
 def test_batch_independence_and_determinism(sep24, dev):
     """row b of a batch == the same window alone (reference: 1.1e-6); bit-identical reruns."""
     from targetdiarization_amd.weights import recipe_wave

@@ -26,12 +26,15 @@
 // Tiling: 256 x 256 x 16 block tile, 8 waves as 2(M) x 4(N), wave tile 128 x 64 = 4 x 2 MFMA
 // tiles (128 accumulator VGPRs), 1 block per CU.  No VALU work in the main loop: operands go
 // global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction, 4 per wave per
-// k-tile) into a ring of FOUR 32 KB stages; the DMA of tile t+3 is issued during the MFMAs of
-// tile t and waited for with a COUNTED vmcnt (never 0 in steady state) before the raw s_barrier
-// that opens stage t+2.  Fragments of tile t+1 are read from LDS during the MFMAs of tile t (A
+// k-tile) into a ring of FOUR 32 KB stages; the DMA of tile t+4 is issued during the MFMAs of
+// tile t — into the buffer tile t itself just left for the registers — and waited for with a
+// COUNTED vmcnt (never 0 in steady state) before the raw s_barrier that opens stage t+3: three
+// stage times of latency tolerance.  The operands mostly hit L2, but a quarter of the requests
+// go to the Infinity Cache / HBM (~3 us under load) and the vmcnt is in order, so the stage time
+// settles at (miss latency) / (stages of look-ahead): 1.5 us with two stages of look-ahead.  Fragments of tile t+1 are read from LDS during the MFMAs of tile t (A
 // fragments into the registers the finished row of MFMA tiles just released, B fragments into
 // a second register set), so a stage is
-//     [vmcnt(4); s_barrier]  4 x { 6 MFMA ; fragment reads ; 1 LDS-DMA }
+//     [vmcnt(8); lgkmcnt(0); s_barrier]  4 x { 6 MFMA ; fragment reads ; 1 LDS-DMA }
 // with nothing exposed but the barrier itself.
 //
 // Two operand formats, chosen per operand by A_TR / B_TR:
@@ -197,6 +200,8 @@ __device__ __forceinline__ void h3_stage(f32x16 (&acc)[4][2], f16x8 (&ah)[4], f1
 #define H3_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define H3_BARRIER()                                   \
     do {                                               \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this wave's fragment reads of the previous stage are done:    \
+                                                              the buffer they came from may be refilled after the barrier */ \
         __builtin_amdgcn_s_barrier();                  \
         asm volatile("" ::: "memory");                 \
         __builtin_amdgcn_sched_barrier(0);             \
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
     const H3Seg& sg0 = g.seg[0];
     const int zz2 = z % sg0.zdiv;
     const int nkt0 = (sg0.kchunk ? max(0, min(sg0.K, sg0.ktotal - zz2 * sg0.kchunk)) : sg0.K) / H3_BK;
-    const int nkt = TWOSEG ? nkt0 + g.seg[1].K / H3_BK : nkt0;      // (TWOSEG: the host guarantees K0 >= 64, K1 >= 48, no kchunk)
+    const int nkt = TWOSEG ? nkt0 + g.seg[1].K / H3_BK : nkt0;      // (TWOSEG: the host guarantees K0 >= 64, K1 >= 64, no kchunk)
     if (nkt > 0) {
         const unsigned char* gp[4];
         long gstep;
@@ -324,14 +329,14 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
             }
         }
 
-        // ---- prologue: tiles 0..2 in flight, fragments of tile 0 in registers
+        // ---- prologue: tiles 0..3 in flight, fragments of tile 0 in registers
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < 4; ++p)
             if (p < nkt0) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) h3_glds16(gp[j] + p * gstep, lds + p * H3_STAGE + sdst + j * 1024);
             }
-        if (nkt0 >= 3) H3_WAIT_VM(8); else if (nkt0 == 2) H3_WAIT_VM(4); else H3_WAIT_VM(0);
+        if (nkt0 >= 4) H3_WAIT_VM(12); else if (nkt0 == 3) H3_WAIT_VM(8); else if (nkt0 == 2) H3_WAIT_VM(4); else H3_WAIT_VM(0);
         H3_BARRIER();
         f16x8 ah[4], al[4], bh[2], bl[2];
 #pragma unroll
@@ -346,17 +351,17 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
         }
 
         // ---- stages.  At the top of stage t the wave's own pieces of tile t+1 must have landed
-        // (tile t+2 may stay in flight: vmcnt(4)); the barrier then makes tile t+1 readable for
-        // everyone and proves that buffer (t+3)&3 — read last during stage t-2 — is free.
+        // (tiles t+2, t+3 may stay in flight: vmcnt(8)); the barrier then makes tile t+1 readable for everyone and —
+        // every wave having retired its reads of tile t (lgkmcnt(0) before the barrier) — frees buffer t&3 for tile t+4.
         // TWOSEG: ONE pipeline over both segments — the DMA switches to the second segment's operands three
         // stages before the MFMAs do, the accumulators are rescaled between stage nkt0-1 and stage nkt0.
 #define H3_STEADY(FULLN, PH, LIMIT, TILE0)                                                                             \
-            for (; t + 3 < (LIMIT); ++t) {                                                                             \
-                H3_WAIT_VM(4);                                                                                         \
+            for (; t + 4 < (LIMIT); ++t) {                                                                             \
+                H3_WAIT_VM(8);                                                                                         \
                 if (VARIANT != 4) H3_BARRIER();                                                                        \
                 h3_stage<A_TR, B_TR, FULLN, VARIANT != 2 && VARIANT != 3, VARIANT != 1 && VARIANT != 3, PH>(           \
-                    acc, ah, al, bh, bl, lds + ((t + 1) & 3) * H3_STAGE, f, gp, (long)(t + 3 - (TILE0)) * gstep,       \
-                    lds + ((t + 3) & 3) * H3_STAGE + sdst);                                                            \
+                    acc, ah, al, bh, bl, lds + ((t + 1) & 3) * H3_STAGE, f, gp, (long)(t + 4 - (TILE0)) * gstep,       \
+                    lds + ((t + 4) & 3) * H3_STAGE + sdst);                                                            \
             }
 #define H3_RUN(FULLN, PH)                                                                                              \
         {                                                                                                              \
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
             if constexpr (TWOSEG) {                                                                                    \
                 H3_STEADY(FULLN, PH, nkt0, 0)                                                                          \
                 setup(g.seg[1], gp, gstep);                                                                            \
-                H3_STEADY(FULLN, PH, nkt0 + 3, nkt0)                                                                   \
+                H3_STEADY(FULLN, PH, nkt0 + 4, nkt0)                                                                   \
                 {                                                                                                      \
                     const H3Seg& s1 = g.seg[1];                                                                        \
                     const float* sb0 = sg0.sb + (long)(z / sg0.zdiv) * sg0.strideSB + (long)zz2 * sg0.strideSB2;       \
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
                 H3_STEADY(FULLN, PH, nkt, 0)                                                                           \
             }                                                                                                          \
             for (; t + 1 < nkt; ++t) {                                                                                 \
-                if (t + 2 < nkt) H3_WAIT_VM(4); else H3_WAIT_VM(0);                                                    \
+                if (t + 3 < nkt) H3_WAIT_VM(8); else if (t + 2 < nkt) H3_WAIT_VM(4); else H3_WAIT_VM(0);                                                    \
                 H3_BARRIER();                                                                                          \
                 h3_stage<A_TR, B_TR, FULLN, true, false, PH>(acc, ah, al, bh, bl, lds + ((t + 1) & 3) * H3_STAGE, f, gp, 0, lds); \
             }                                                                                                          \
@@ -531,7 +536,7 @@ inline hipError_t launch_gemm_h3x(H3Args g, int batches, Epi epi, hipStream_t st
         g.mp = 0; g.gw = 1;
         grid = dim3(8 * ((batches + 7) / 8) * g.tiles_m * g.tiles_n, 1, 1);
     }
-    if (TWOSEG && (g.seg[0].K < 64 || g.seg[1].K < 48 || g.seg[0].kchunk || g.seg[1].kchunk)) return hipErrorInvalidValue;
+    if (TWOSEG && (g.seg[0].K < 64 || g.seg[1].K < 64 || g.seg[0].kchunk || g.seg[1].kchunk)) return hipErrorInvalidValue;
     hipLaunchKernelGGL((gemm_h3_kernel<A_TR, B_TR, PAIRED, TWOSEG, Epi, VARIANT>), grid, dim3(H3_THREADS), H3_LDS + (TWOSEG ? 1024 : 0), st, g, epi);
     return hipGetLastError();
 }

@@ -1110,3 +1110,48 @@ int tdx_cosine_scores(const float* emb, const float* ref, int N, int D, float* s
 }
 
 }  // extern "C"
+
+// ---- diagnostic: per-CU operand fill rate, LDS-DMA vs register staging (tools/fill_bench.py) -------------
+namespace {
+template <int MODE>      // 0: global_load_lds_dwordx4 ; 1: global_load_dwordx4 + ds_write_b128
+__global__ __launch_bounds__(512, 2) void fill_bench_kernel(const unsigned char* __restrict__ src, long bytes_per_block, int iters, float* sink) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned char* base = src + (long)blockIdx.x * bytes_per_block;
+    const long span = bytes_per_block / 32768;        // 32 KB tiles in this block's slab
+    float acc = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        const unsigned char* tile = base + (long)(it % span) * 32768;
+        unsigned char* dst = lds + (it & 3) * 32768;
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tile + (wave * 4 + j) * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(dst + (wave * 4 + j) * 1024), 16, 0, 0);
+            if ((it & 1) == 1) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+        } else {
+            tdx::f32x4 r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = *reinterpret_cast<const tdx::f32x4*>(tile + (wave * 4 + j) * 1024 + lane * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<tdx::f32x4*>(dst + (wave * 4 + j) * 1024 + lane * 16) = r[j];
+            if ((it & 1) == 1) __builtin_amdgcn_s_barrier();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    acc += reinterpret_cast<const float*>(lds)[threadIdx.x];
+    if (acc == 123.456f) sink[0] = acc;
+}
+}  // namespace
+extern "C" int tdx_fill_bench(int mode, const void* src, long bytes_per_block, int blocks, int iters, float* sink, void* stream) {
+    static bool set = false;
+    if (!set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&fill_bench_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&fill_bench_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        set = true;
+    }
+    if (mode == 0) hipLaunchKernelGGL(fill_bench_kernel<0>, dim3(blocks), dim3(512), 131072, (hipStream_t)stream, (const unsigned char*)src, bytes_per_block, iters, sink);
+    else hipLaunchKernelGGL(fill_bench_kernel<1>, dim3(blocks), dim3(512), 131072, (hipStream_t)stream, (const unsigned char*)src, bytes_per_block, iters, sink);
+    return hipGetLastError() == hipSuccess ? TDX_OK : TDX_E_HIP;
+}

@@ -89,6 +89,54 @@ def cpu_baseline(sd, wave_np, budget_windows: int):
                       f"(the reference's own batch size), oracle/mossformer2_oracle.py, torch CPU fp32, {dt:.1f}s wall"}
 
 
+def cfg5_bench(args):
+    """BASELINE configs[4] (scaled: --utterances per GPU instead of 1000 in total): utterance i lives on rank
+    i % P, each utterance = three 10 s windows through MossFormer2, ERes2NetV2 on both separated streams, ONE
+    all-gather of the [n_i*2,192] embedding blocks (RCCL over xGMI).  Host arrays in, host arrays out (the
+    boundary of `pipeline.HotPath.run`), so this number includes PCIe."""
+    import torch.distributed as dist
+    from targetdiarization_amd.pipeline import HotPath, shard_indices
+    from targetdiarization_amd.weights import recipe_eres2netv2_state_dict, recipe_state_dict
+    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    hp = HotPath(recipe_state_dict(0, 24), recipe_eres2netv2_state_dict(0), None, cuda_device=local_rank)
+    n_total = args.utterances * world
+    mine = shard_indices(n_total, rank, world)
+    utts = [synth_mixtures(1, 480000, seed=5 + i)[0] for i in mine]
+    target = np.random.default_rng(5).standard_normal(192).astype(np.float32)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        hp.run(utts[:2], target, rank, world, 2 * world, with_asr=False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = hp.run(utts, target, rank, world, n_total, with_asr=False)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    assert out["embeddings"].shape == (n_total * 2, 192) and np.isfinite(out["scores"]).all()
+    if rank == 0:
+        print(json.dumps({"metric": "real-time factor (audio-sec/wall-sec), hot path cfg5 (host arrays in/out)", "value": n_total * 30.0 * args.steps / dt,
+                          "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": f"BASELINE configs[4] scaled: {n_total} x 30 s utterances, utterance i on rank i % {world}, "
+                                                 "MossFormer2 (3 windows each) -> ERes2NetV2 on both streams -> all-gather of [n*2,192] embeddings "
+                                                 "-> cosine scores; recipe weights",
+                                     "utterances_per_gpu": args.utterances}}), flush=True)
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
 def pipeline_bench(args):
     """BASELINE configs[2]/[3] at window granularity, device-resident: every 10 s window goes
     H1 -> (both separated streams) H2 + cosine [-> H3 encoder]; windows are independent units."""
@@ -175,10 +223,13 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"],
+    ap.add_argument("--utterances", type=int, default=16, help="cfg5: 30 s utterances per GPU (BASELINE config 5 has 1000 in total)")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
                     help="cfg2 (default, the headline config): separation only; cfg3: + ERes2NetV2 embeddings + cosine "
                          "on 10 min of audio; cfg4: + Paraformer encoder on 30 min.  cfg3/cfg4 are extra measurements.")
     args = ap.parse_args()
+    if args.workload == "cfg5":
+        return cfg5_bench(args)
     if args.workload != "cfg2":
         return pipeline_bench(args)
 

@@ -197,6 +197,15 @@ __device__ __forceinline__ void h3_stage(f32x16 (&acc)[4][2], f16x8 (&ah)[4], f1
     }
 }
 
+// a wave whose 128 rows all lie beyond M (M <= 128 launches: lin_k^T [v|u]) only keeps feeding the ring
+template <bool ISSUE>
+__device__ __forceinline__ void h3_stage_dma_only(const unsigned char* const (&gp)[4], long goff, unsigned char* dmad) {
+    if constexpr (ISSUE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h3_glds16(gp[j] + goff, dmad + j * 1024);
+    }
+}
+
 #define H3_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define H3_BARRIER()                                   \
     do {                                               \
@@ -269,6 +278,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
         f.bpl[0] = f.apl[0]; f.bpl[1] = f.apl[1];
     }
     const bool full_n = PAIRED || (n0 + 128 < g.N);
+    const bool wave_on = m0 + wm * 128 < g.M;       // (wave-uniform) this wave's 128 rows exist
 
     // per-lane DMA source pointers of a segment's first k-tile (gp) and their advance per k-tile (gstep)
     auto setup = [&](const H3Seg& sg, const unsigned char* (&gp)[4], long& gstep) {
@@ -359,9 +369,13 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
             for (; t + 4 < (LIMIT); ++t) {                                                                             \
                 H3_WAIT_VM(8);                                                                                         \
                 if (VARIANT != 4) H3_BARRIER();                                                                        \
-                h3_stage<A_TR, B_TR, FULLN, VARIANT != 2 && VARIANT != 3, VARIANT != 1 && VARIANT != 3, PH>(           \
-                    acc, ah, al, bh, bl, lds + ((t + 1) & 3) * H3_STAGE, f, gp, (long)(t + 4 - (TILE0)) * gstep,       \
-                    lds + ((t + 4) & 3) * H3_STAGE + sdst);                                                            \
+                if (wave_on)                                                                                           \
+                    h3_stage<A_TR, B_TR, FULLN, VARIANT != 2 && VARIANT != 3, VARIANT != 1 && VARIANT != 3, PH>(       \
+                        acc, ah, al, bh, bl, lds + ((t + 1) & 3) * H3_STAGE, f, gp, (long)(t + 4 - (TILE0)) * gstep,   \
+                        lds + ((t + 4) & 3) * H3_STAGE + sdst);                                                        \
+                else                                                                                                   \
+                    h3_stage_dma_only<VARIANT != 1 && VARIANT != 3>(gp, (long)(t + 4 - (TILE0)) * gstep,               \
+                                                                    lds + ((t + 4) & 3) * H3_STAGE + sdst);            \
             }
 #define H3_RUN(FULLN, PH)                                                                                              \
         {                                                                                                              \
@@ -397,9 +411,9 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
             for (; t + 1 < nkt; ++t) {                                                                                 \
                 if (t + 3 < nkt) H3_WAIT_VM(8); else if (t + 2 < nkt) H3_WAIT_VM(4); else H3_WAIT_VM(0);                                                    \
                 H3_BARRIER();                                                                                          \
-                h3_stage<A_TR, B_TR, FULLN, true, false, PH>(acc, ah, al, bh, bl, lds + ((t + 1) & 3) * H3_STAGE, f, gp, 0, lds); \
+                if (wave_on) h3_stage<A_TR, B_TR, FULLN, true, false, PH>(acc, ah, al, bh, bl, lds + ((t + 1) & 3) * H3_STAGE, f, gp, 0, lds); \
             }                                                                                                          \
-            h3_stage<A_TR, B_TR, FULLN, false, false, PH>(acc, ah, al, bh, bl, lds, f, gp, 0, lds);                    \
+            if (wave_on) h3_stage<A_TR, B_TR, FULLN, false, false, PH>(acc, ah, al, bh, bl, lds, f, gp, 0, lds);       \
         }
         // the two waves of a SIMD (w and w+4) issue their DMA in different halves of the stage
         if (full_n) { if (stB) H3_RUN(true, 1) else H3_RUN(true, 0) }

@@ -416,9 +416,9 @@ __global__ __launch_bounds__(256) void fsmn_tail_kernel(const float* __restrict_
     if (lane == 0) hs[m] = inv;
 }
 
-// x3 path: kvuT[b][ch][d] = (sum_sp slab[b][sp][ch][d]) / S in fp32, and per block the max |value| (bmax[b][block];
+// x3 path: kvu[b][d][ch] = (sum_sp slab[b][sp][d][ch]) / S in fp32, and per block the max |value| (bmax[b][block];
 // no atomics: 1024 waves hammering one word cost 250 us).  Then kvu_planes_kernel reduces the block maxima and
-// re-writes kvuT as K-major planes KvuP[b][d][16][2][128] with one exact power-of-two scale per sample (the B
+// re-writes kvu as K-major planes KvuP[b][d][16][2][128] with one exact power-of-two scale per sample (the B
 // operand of the attention GEMM's linear segment).
 __global__ __launch_bounds__(256) void kvu_reduce_t_kernel(const float* __restrict__ slab, float* __restrict__ kvu, int splits, long per,
                                                             float S, float* __restrict__ bmax) {
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void kvu_reduce_t_kernel(const float* __restri
 }
 __global__ __launch_bounds__(256) void kvu_planes_kernel(const float* __restrict__ kvu, const float* __restrict__ bmax, int nbmax,
                                                           unsigned char* __restrict__ planes, float* __restrict__ scale, int E2) {
-    // thread = (d, 8 consecutive ch); kvu[b] is [E2 ch][128 d]
+    // thread = (d, 8 consecutive ch); kvu[b] is [128 d][E2 ch]
     __shared__ float wmax[4];
     const int b = blockIdx.y;
     float mu = 0.f;
@@ -459,11 +459,11 @@ __global__ __launch_bounds__(256) void kvu_planes_kernel(const float* __restrict
     const int d = i / per, ch = (i - d * per) * 8;
     float inv;
     const float s = h3_row_scale(mu, inv);
-    const float* src = kvu + (long)b * E2 * 128 + (long)ch * 128 + d;
+    const float* src = kvu + (long)b * E2 * 128 + (long)d * E2 + ch;
     f16x8 hi, lo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float xs = src[j * 128] * s;
+        const float xs = src[j] * s;
         const _Float16 t = (_Float16)xs;
         hi[j] = t; lo[j] = (_Float16)(xs - (float)t);
     }

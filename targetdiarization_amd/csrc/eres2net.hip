@@ -17,6 +17,7 @@
 
 #include "../../include/tdx.h"
 #include "gemm.hpp"
+#include "gemm_h3.hpp"
 #include "devutil.hpp"
 #include "tdx_common.hpp"
 
@@ -150,7 +151,10 @@ struct EpiAffGate {     // att = 1 + tanh(v+b); out = x*att + y*(2-att), columns
     }
 };
 
-struct ConvW { size_t w, b; int N, Npad, cin, cinp, taps; };
+struct ConvW {
+    size_t w, b; int N, Npad, cin, cinp, taps;
+    const unsigned char* hp = nullptr; const float* hs = nullptr;     // split-f16 planes [Npad][taps*cinp] + row scales (x3 core), if made
+};
 struct AffW { ConvW c0, c3; int C, inter, ipad; };
 struct BlockW { ConvW conv1, convs[4], conv3, sc; bool has_sc; AffW aff[3]; int stride, cin, width, wpad, w4, cout; bool is_aff; };
 
@@ -165,10 +169,29 @@ int conv_gemm(const float* A, long lda, const float* dev, const ConvW& cw, int B
     return TDX_OK;
 }
 
+// the same convolution on the split-f16 x3 core (gemm_h3.hpp, A_CONV): Ap = planes of the NHWC input with ONE scale
+// (*inv_scale on the device) — activations here are ReLU20-bounded, and the taps of a 3x3 read different pixel rows into
+// one accumulator row, so a per-row scale could not be used anyway
+template <class Epi>
+int conv_gemm_h3(const unsigned char* Ap, const float* inv_scale, const unsigned char* zero_row, const ConvW& cw, int B, int Hin, int Win,
+                 int Hout, int Wout, int stride, Epi e, hipStream_t st) {
+    const long M = (long)B * Hout * Wout;
+    H3Args g{};
+    g.seg[0] = h3_seg(Ap, inv_scale, 4L * cw.cinp, cw.hp, cw.hs, 4L * cw.taps * cw.cinp, cw.taps * cw.cinp);
+    g.seg[0].sa_mul = 0;
+    g.nseg = 1; g.M = (int)M; g.N = cw.Npad;
+    g.cv_Hin = Hin; g.cv_Win = Win; g.cv_Hout = Hout; g.cv_Wout = Wout; g.cv_stride = stride; g.cv_ntaps = cw.taps; g.cv_cin = cw.cinp;
+    g.zero_row = zero_row;
+    if (launch_gemm_h3x<false, false, false, false, Epi, 0, true>(g, 1, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    return TDX_OK;
+}
+
 }  // namespace
 
 struct tdx_eres2net {
     float* dev; std::vector<BlockW> blocks; size_t stem_w, stem_b, seg_w, seg_b; ConvW ds; AffW fuse34;
+    unsigned char* dev_planes = nullptr;      // x3 planes of the stage-3/4 and layer3_ds convolution weights
+    size_t consts = 0;                        // dev + consts: {2^-10, 2^-9} inverse static scales, then 8 KB of zeros (halo row)
 };
 
 namespace {
@@ -282,6 +305,10 @@ int tdx_eres2net_create(const void* blob, size_t blob_bytes, int device, tdx_ere
         const float* sb = get("seg_1.bias", EMB);
         if (sb) memcpy(host.data() + h->seg_b, sb, EMB * sizeof(float));
     }
+    h->consts = host.size();
+    host.resize(host.size() + al(64 + 2048), 0.f);
+    host[h->consts] = 1.0f / 1024.0f;      // activations <= 20 (ReLU20): x * 2^10 < 2^15
+    host[h->consts + 1] = 1.0f / 512.0f;   // sums of two such (Res2Net chain inputs, AFF outputs) <= 40: x * 2^9 < 2^15
     if (!ok) { delete h; return tdx::fail(TDX_E_BLOB, "tdx_eres2net_create: tensor missing or wrong size: " + missing); }
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { delete h; return tdx::fail_hip(e, __FILE__, __LINE__); }
@@ -289,23 +316,55 @@ int tdx_eres2net_create(const void* blob, size_t blob_bytes, int device, tdx_ere
     if (e != hipSuccess) { delete h; return tdx::fail_hip(e, __FILE__, __LINE__); }
     e = hipMemcpy(h->dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) { hipFree(h->dev); delete h; return tdx::fail_hip(e, __FILE__, __LINE__); }
+    {   // x3 planes of the compute-heavy convolutions (stages 3-4: K >= 96 per tap; layer3_ds), split once
+        std::vector<ConvW*> jobs;
+        size_t bi = 0;
+        for (int s = 0; s < NSTAGE; ++s)
+            for (int i = 0; i < kBlocks[s]; ++i, ++bi) {
+                if (s < 2) continue;
+                BlockW& b = h->blocks[bi];
+                jobs.push_back(&b.conv1); if (b.has_sc) jobs.push_back(&b.sc);
+                for (int j = 0; j < SCALE; ++j) jobs.push_back(&b.convs[j]);
+                jobs.push_back(&b.conv3);
+            }
+        jobs.push_back(&h->ds);
+        size_t bytes = 0;
+        for (ConvW* c : jobs) bytes += (size_t)c->Npad * c->taps * c->cinp * 4 + al(c->Npad) * 4;
+        e = hipMalloc(&h->dev_planes, bytes);
+        if (e != hipSuccess) { hipFree(h->dev); delete h; return tdx::fail_hip(e, __FILE__, __LINE__); }
+        unsigned char* q = h->dev_planes;
+        for (ConvW* c : jobs) {
+            const int K = c->taps * c->cinp;
+            float* sc = (float*)(q + (size_t)c->Npad * K * 4);
+            e = tdx::launch_h3_split_rows_long(h->dev + c->w, K, q, sc, c->Npad, K, nullptr);
+            if (e != hipSuccess) { hipFree(h->dev_planes); hipFree(h->dev); delete h; return tdx::fail_hip(e, __FILE__, __LINE__); }
+            c->hp = q; c->hs = sc;
+            q += (size_t)c->Npad * K * 4 + al(c->Npad) * 4;
+        }
+        e = hipDeviceSynchronize();
+        if (e != hipSuccess) { hipFree(h->dev_planes); hipFree(h->dev); delete h; return tdx::fail_hip(e, __FILE__, __LINE__); }
+    }
     *out = h;
     return TDX_OK;
 }
 
 int tdx_eres2net_destroy(tdx_eres2net* h) {
-    if (h) { if (h->dev) hipFree(h->dev); delete h; }
+    if (h) { if (h->dev_planes) hipFree(h->dev_planes); if (h->dev) hipFree(h->dev); delete h; }
     return TDX_OK;
 }
 
 namespace {
-struct WsPlan { size_t P, keep3, o1, spin, tbuf, stats, total; };
+struct WsPlan { size_t P, keep3, o1, spin, tbuf, stats, hx, hcat, hin, total; };
 inline WsPlan ws_plan(const tdx_eres2net* h, int B, int F) {
     const Dims d = make_dims(F);
-    WsPlan w{}; size_t mP = (size_t)B * 80 * F * 64, mo1 = 0, msp = 0, mt = 0;
+    WsPlan w{}; size_t mP = (size_t)B * 80 * F * 64, mo1 = 0, msp = 0, mt = 0, mhx = 0, mhc = 0, mhi = 0;
     int s = 0, cnt = 0;
     for (const BlockW& b : h->blocks) {
         const size_t rows = (size_t)B * d.H[s + 1] * d.W[s + 1];
+        if (s >= 2) {      // planes of the x3 convolutions' inputs: block input, concatenated chain outputs, chain-conv input
+            const size_t rows_in = cnt == 0 ? (size_t)B * d.H[s] * d.W[s] : rows;
+            mhx = std::max(mhx, rows_in * b.cin); mhc = std::max(mhc, rows * b.w4); mhi = std::max(mhi, rows * b.wpad);
+        }
         mP = std::max(mP, rows * b.cout); mo1 = std::max(mo1, rows * b.w4); msp = std::max(msp, rows * b.wpad);
         if (b.is_aff) mt = std::max(mt, rows * (size_t)b.aff[0].ipad);
         if (++cnt == kBlocks[s]) { cnt = 0; ++s; }
@@ -314,7 +373,9 @@ inline WsPlan ws_plan(const tdx_eres2net* h, int B, int F) {
     mt = std::max(mt, rows4 * 512);
     w.P = al(mP + 4096); w.keep3 = al(rows3 * 1024 + 4096); w.o1 = al(mo1 + 4096); w.spin = al(msp + 4096); w.tbuf = al(mt + 4096);
     w.stats = al((size_t)B * 40960);
-    w.total = 3 * w.P + w.keep3 + 2 * w.o1 + 2 * w.spin + w.tbuf + w.stats;
+    mhx = std::max(mhx, rows3 * 1024);
+    w.hx = al(mhx + 4096); w.hcat = al(mhc + 4096); w.hin = al(mhi + 4096);
+    w.total = 3 * w.P + w.keep3 + 2 * w.o1 + 2 * w.spin + w.tbuf + w.stats + w.hx + w.hcat + w.hin;
     return w;
 }
 }  // namespace
@@ -354,6 +415,12 @@ int tdx_eres2net_forward(tdx_eres2net* h, const float* feat, int B, int F, float
     float* o1 = keep3 + wp.keep3; float* cat = o1 + wp.o1;
     float* spin[2] = {cat + wp.o1, cat + wp.o1 + wp.spin};
     float* tbuf = spin[1] + wp.spin; float* stats = tbuf + wp.tbuf;
+    unsigned char* hx = (unsigned char*)(stats + wp.stats);
+    unsigned char* hcat = hx + wp.hx * sizeof(float);
+    unsigned char* hin = hcat + wp.hcat * sizeof(float);
+    const float* inv20 = h->dev + h->consts;            // 2^-10
+    const float* inv40 = h->dev + h->consts + 1;        // 2^-9
+    const unsigned char* zero_row = (const unsigned char*)(h->dev + h->consts + 64);
 
     hipLaunchKernelGGL(stem_kernel, dim3((unsigned)((rows1 * 16 + 255) / 256)), dim3(256), 0, st, feat, h->dev + h->stem_w, h->dev + h->stem_b, P[0], F, (long)rows1);
     LAUNCH_CHECK();
@@ -368,12 +435,24 @@ int tdx_eres2net_forward(tdx_eres2net* h, const float* feat, int B, int F, float
         const int iy = cur < 0 ? 0 : (cur + 1) % 3, ir = cur < 0 ? 1 : (cur + 2) % 3;
         float* y = last_of_stage3 ? keep3 : P[iy];
         float* res = P[ir];
-        // conv1 (1x1, stride) + bn1 + relu20 -> o1 [M, w4]
-        TRY(conv_gemm(x, b.cin, h->dev, b.conv1, B, Hin, Win, Ho, Wo, b.stride, EpiRelu20{h->dev + b.conv1.b, o1, b.w4, b.w4}, st));
+        const bool x3 = b.conv1.hp != nullptr;          // stages 3-4: the convolutions run on the split-f16 x3 core
         const float* resid = x;
-        if (b.has_sc) {
-            TRY(conv_gemm(x, b.cin, h->dev, b.sc, B, Hin, Win, Ho, Wo, b.stride, EpiBiasG{h->dev + b.sc.b, res, b.cout, b.cout}, st));
-            resid = res;
+        if (x3) {
+            // block input (ReLU20 output, <= 20) as planes with the static scale 2^10, shared by conv1 and the shortcut
+            if (tdx::launch_h3_split_rows_static(x, b.cin, hx, (long)B * Hin * Win, b.cin, 1024.0f, st) != hipSuccess)
+                return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+            TRY(conv_gemm_h3(hx, inv20, zero_row, b.conv1, B, Hin, Win, Ho, Wo, b.stride, EpiRelu20{h->dev + b.conv1.b, o1, b.w4, b.w4}, st));
+            if (b.has_sc) {
+                TRY(conv_gemm_h3(hx, inv20, zero_row, b.sc, B, Hin, Win, Ho, Wo, b.stride, EpiBiasG{h->dev + b.sc.b, res, b.cout, b.cout}, st));
+                resid = res;
+            }
+        } else {
+            // conv1 (1x1, stride) + bn1 + relu20 -> o1 [M, w4]
+            TRY(conv_gemm(x, b.cin, h->dev, b.conv1, B, Hin, Win, Ho, Wo, b.stride, EpiRelu20{h->dev + b.conv1.b, o1, b.w4, b.w4}, st));
+            if (b.has_sc) {
+                TRY(conv_gemm(x, b.cin, h->dev, b.sc, B, Hin, Win, Ho, Wo, b.stride, EpiBiasG{h->dev + b.sc.b, res, b.cout, b.cout}, st));
+                resid = res;
+            }
         }
         // Res2Net chain: conv_j reads in_j (o1 chunk 0 in place, later spin[j&1]) and its epilogue
         // writes sp_j into cat and, for the plain-add stages, in_{j+1} = sp_j + spx[j+1] into spin[(j+1)&1]
@@ -383,11 +462,21 @@ int tdx_eres2net_forward(tdx_eres2net* h, const float* feat, int B, int F, float
             const bool plain_next = (j + 1 < SCALE) && !b.is_aff;
             EpiChain e{h->dev + b.convs[j].b, cat, b.w4, j * b.width, b.width, b.wpad, o1, b.w4, (j + 1) * b.width,
                        plain_next ? spin[(j + 1) & 1] : nullptr};
-            TRY(conv_gemm(in, ldin, h->dev, b.convs[j], B, Ho, Wo, Ho, Wo, 1, e, st));
+            if (x3) {     // chain input = sum of two ReLU20 outputs or an AFF blend of them (<= 40): static scale 2^9
+                if (tdx::launch_h3_split_rows_static(in, ldin, hin, M, b.wpad, 512.0f, st) != hipSuccess)
+                    return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+                TRY(conv_gemm_h3(hin, inv40, zero_row, b.convs[j], B, Ho, Wo, Ho, Wo, 1, e, st));
+            } else {
+                TRY(conv_gemm(in, ldin, h->dev, b.convs[j], B, Ho, Wo, Ho, Wo, 1, e, st));
+            }
             if (b.is_aff && j + 1 < SCALE)      // in_{j+1} = AFF(sp_j, spx[j+1])
                 TRY(run_aff(h, b.aff[j], cat + j * b.width, b.w4, o1 + (j + 1) * b.width, b.w4, tbuf, spin[(j + 1) & 1], b.wpad, M, st));
         }
-        {   // conv3 + bn3 + residual + relu20 -> y
+        if (x3) {   // conv3 + bn3 + residual + relu20 -> y   (cat = ReLU20 outputs)
+            if (tdx::launch_h3_split_rows_static(cat, b.w4, hcat, M, b.w4, 1024.0f, st) != hipSuccess)
+                return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+            TRY(conv_gemm_h3(hcat, inv20, zero_row, b.conv3, B, Ho, Wo, Ho, Wo, 1, EpiConv3{h->dev + b.conv3.b, resid, y, b.cout}, st));
+        } else {
             GemmArgs g = make_args((int)M, b.conv3.Npad, make_seg(cat, b.w4, h->dev + b.conv3.w, b.conv3.cinp, b.conv3.cinp));
             if (launch_gemm<false, false, false, false>(g, 1, EpiConv3{h->dev + b.conv3.b, resid, y, b.cout}, st) != hipSuccess)
                 return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
@@ -399,7 +488,9 @@ int tdx_eres2net_forward(tdx_eres2net* h, const float* feat, int B, int F, float
     // layer3_ds (3x3 stride 2) on out3, fuse34 = AFF(out4, out3_ds), TSTP, seg_1
     const int i_ds = (cur + 1) % 3, i_fu = (cur + 2) % 3;
     const long M4 = (long)B * d.H[4] * d.W[4];
-    TRY(conv_gemm(keep3, 1024, h->dev, h->ds, B, d.H[3], d.W[3], d.H[4], d.W[4], 2, EpiBiasG{nullptr, P[i_ds], 2048, 2048}, st));
+    if (tdx::launch_h3_split_rows_static(keep3, 1024, hx, (long)B * d.H[3] * d.W[3], 1024, 1024.0f, st) != hipSuccess)
+        return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    TRY(conv_gemm_h3(hx, inv20, zero_row, h->ds, B, d.H[3], d.W[3], d.H[4], d.W[4], 2, EpiBiasG{nullptr, P[i_ds], 2048, 2048}, st));
     TRY(run_aff(h, h->fuse34, x, 2048, P[i_ds], 2048, tbuf, P[i_fu], 2048, M4, st));
     hipLaunchKernelGGL(tstp_kernel, dim3(d.H[4], B), dim3(256), 0, st, P[i_fu], stats, d.W[4], 2048, d.H[4]);
     LAUNCH_CHECK();

@@ -90,6 +90,11 @@ struct H3Args {
     int tiles_m, tiles_n;
     int map_mode, mp, gw, batches;
     int pair_off;
+    // A_CONV (implicit GEMM over NHWC pixel rows): output row m = (b, h, w) of [B, Hout, Wout]; K segment `tap` (cv_cin
+    // values) reads the planes row of input pixel (b, h*stride+dy, w*stride+dx), (dy,dx) = (tap/3-1, tap%3-1) for 9
+    // taps or (0,0) for 1, or `zero_row` (>= 4*cv_cin zero bytes) outside the image; B = [N][ntaps*cv_cin] planes.
+    int cv_Hin, cv_Win, cv_Hout, cv_Wout, cv_stride, cv_ntaps, cv_cin;
+    const unsigned char* zero_row;
 };
 
 inline H3Seg h3_seg(const void* A, const float* sa, long lda, const void* B, const float* sb, long ldb, int K) {
@@ -219,8 +224,9 @@ __device__ __forceinline__ void h3_stage_dma_only(const unsigned char* const (&g
 // A_TR / B_TR: operand in K-major planes.  TWOSEG: two K segments (same operand formats, their own
 // pointers and scales).  VARIANT != 0: timing-only diagnostics (wrong results): 1 no LDS-DMA in
 // the loop, 2 no fragment reads, 3 neither, 4 no barrier.
-template <bool A_TR, bool B_TR, bool PAIRED, bool TWOSEG, class Epi, int VARIANT = 0>
+template <bool A_TR, bool B_TR, bool PAIRED, bool TWOSEG, class Epi, int VARIANT = 0, bool A_CONV = false>
 __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi epi) {
+    static_assert(!A_CONV || (!A_TR && !TWOSEG), "A_CONV: row-major A planes, one weight segment");
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -319,6 +325,23 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
         }
     };
 
+    // A_CONV: the A-loader waves' source pointers for one tap (k = 0 of the tap's cv_cin values)
+    auto setup_conv = [&](int tap, const unsigned char* (&gp)[4]) {
+        const int dy = g.cv_ntaps == 9 ? tap / 3 - 1 : 0, dx = g.cv_ntaps == 9 ? tap - (tap / 3) * 3 - 1 : 0;
+        const int hw = g.cv_Hout * g.cv_Wout;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (wave & 3) * 64 + (lane >> 2) + 16 * j;
+            const int m = min(m0 + r, g.M - 1);
+            const int b_ = m / hw, r_ = m - b_ * hw;
+            const int h_ = r_ / g.cv_Wout, w_ = r_ - h_ * g.cv_Wout;
+            const int ih = h_ * g.cv_stride + dy, iw = w_ * g.cv_stride + dx;
+            const bool ok = ih >= 0 && ih < g.cv_Hin && iw >= 0 && iw < g.cv_Win;
+            const unsigned char* row = ok ? g.seg[0].A + ((long)b_ * g.cv_Hin * g.cv_Win + (long)ih * g.cv_Win + iw) * g.seg[0].lda : g.zero_row;
+            gp[j] = row + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
+        }
+    };
+
     const H3Seg& sg0 = g.seg[0];
     const int zz2 = z % sg0.zdiv;
     const int nkt0 = (sg0.kchunk ? max(0, min(sg0.K, sg0.ktotal - zz2 * sg0.kchunk)) : sg0.K) / H3_BK;
@@ -327,6 +350,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
         const unsigned char* gp[4];
         long gstep;
         setup(sg0, gp, gstep);
+        if constexpr (A_CONV) { if (!stB) setup_conv(0, gp); }
         if constexpr (TWOSEG) {
             // acc changes its scale domain between the segments (sum/(sa0[m]*sb0[n]) -> units of sa1[m]*sb1[n]; powers of
             // two, exact).  The row factors wait in the 1 KiB of LDS behind the stage ring.
@@ -405,6 +429,15 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
                         }                                                                                              \
                 }                                                                                                      \
                 H3_STEADY(FULLN, PH, nkt, nkt0)                                                                        \
+            } else if constexpr (A_CONV) {                                                                             \
+                /* one pipeline over the taps: the A loaders re-aim at the next tap's pixel rows four stages before */ \
+                /* the MFMAs get there; the weight rows (B) run straight through K = ntaps * cv_cin                  */ \
+                const int nk = g.cv_cin / H3_BK;                                                                       \
+                for (int tap = 0; tap < g.cv_ntaps; ++tap) {                                                           \
+                    if (tap > 0 && !stB) setup_conv(tap, gp);                                                          \
+                    const int tile0 = stB ? 0 : tap * nk;                                                              \
+                    H3_STEADY(FULLN, PH, (tap + 1) * nk, tile0)                                                        \
+                }                                                                                                      \
             } else {                                                                                                   \
                 H3_STEADY(FULLN, PH, nkt, 0)                                                                           \
             }                                                                                                          \
@@ -523,11 +556,11 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
     }
 }
 
-template <bool A_TR, bool B_TR, bool PAIRED, bool TWOSEG, class Epi, int VARIANT = 0>
+template <bool A_TR, bool B_TR, bool PAIRED, bool TWOSEG, class Epi, int VARIANT = 0, bool A_CONV = false>
 inline hipError_t launch_gemm_h3x(H3Args g, int batches, Epi epi, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_kernel<A_TR, B_TR, PAIRED, TWOSEG, Epi, VARIANT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_kernel<A_TR, B_TR, PAIRED, TWOSEG, Epi, VARIANT, A_CONV>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             H3_LDS + (TWOSEG ? 1024 : 0));
         attr_set = true;
     }
@@ -551,7 +584,8 @@ inline hipError_t launch_gemm_h3x(H3Args g, int batches, Epi epi, hipStream_t st
         grid = dim3(8 * ((batches + 7) / 8) * g.tiles_m * g.tiles_n, 1, 1);
     }
     if (TWOSEG && (g.seg[0].K < 64 || g.seg[1].K < 64 || g.seg[0].kchunk || g.seg[1].kchunk)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((gemm_h3_kernel<A_TR, B_TR, PAIRED, TWOSEG, Epi, VARIANT>), grid, dim3(H3_THREADS), H3_LDS + (TWOSEG ? 1024 : 0), st, g, epi);
+    if (A_CONV && (g.cv_cin < 64 || g.cv_cin % 16 || g.seg[0].K != g.cv_ntaps * g.cv_cin || !g.zero_row || batches != 1)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((gemm_h3_kernel<A_TR, B_TR, PAIRED, TWOSEG, Epi, VARIANT, A_CONV>), grid, dim3(H3_THREADS), H3_LDS + (TWOSEG ? 1024 : 0), st, g, epi);
     return hipGetLastError();
 }
 
@@ -648,6 +682,62 @@ __global__ __launch_bounds__(256) void h3_split_rows_kernel(const float* __restr
         if (ch < nch) h3_store_chunk(pr + ch * 32, v[c], s);
     }
     if (lane == 0) scale[row] = inv;
+}
+
+// row-major planes with ONE caller-chosen power-of-two scale s (max|x|*s < 65504) for the whole tensor: for tensors with a
+// known bound (ReLU20 activations) and for operands that need one scale along M (the taps of an implicit-GEMM
+// convolution read different pixel rows into the same accumulator row).  K % 8 == 0; columns K..Kp-1 are zero.
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void h3_split_rows_static_kernel(const float* __restrict__ x, long ld, unsigned char* __restrict__ planes,
+                                                                  long R, int K, int Kp, float s) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;       // (row, 8-value chunk)
+    const int per = Kp / 8;
+    if (i >= R * per) return;
+    const long row = i / per;
+    const int ch = (int)(i - row * per);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    if (ch * 8 < K) {
+        const f32x4 a = ldg4(x + row * ld + ch * 8), b = ldg4(x + row * ld + ch * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+    }
+    h3_store_chunk(planes + row * (long)Kp * 4 + ch * 32, v, s);
+}
+inline hipError_t launch_h3_split_rows_static(const float* x, long ld, void* planes, long R, int K, float s, hipStream_t st) {
+    const int Kp = (K + 15) / 16 * 16;
+    const long n = R * (Kp / 8);
+    hipLaunchKernelGGL(h3_split_rows_static_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, ld, (unsigned char*)planes, R, K, Kp, s);
+    return hipGetLastError();
+}
+
+// long rows (weights with K > 2048, e.g. a 3x3 convolution over 1024 channels): one 256-thread block per row,
+// two passes over the row (max, then split).  K % 8 == 0, K % 16 == 0.
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void h3_split_rows_long_kernel(const float* __restrict__ x, long ld, unsigned char* __restrict__ planes,
+                                                                float* __restrict__ scale, int K) {
+    __shared__ float wmax[4];
+    const long row = blockIdx.x;
+    const float* xr = x + row * ld;
+    float mu = 0.f;
+    for (int k = threadIdx.x * 4; k < K; k += 1024) mu = fmaxf(mu, h3_absmax4(*reinterpret_cast<const float4*>(xr + k)));
+    mu = h3_wave_max(mu);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mu;
+    __syncthreads();
+    mu = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    float inv;
+    const float s = h3_row_scale(mu, inv);
+    for (int ch = threadIdx.x; ch < K / 8; ch += 256) {
+        const f32x4 a = ldg4(xr + ch * 8), b = ldg4(xr + ch * 8 + 4);
+        const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        h3_store_chunk(planes + row * (long)K * 4 + ch * 32, v, s);
+    }
+    if (threadIdx.x == 0) scale[row] = inv;
+}
+inline hipError_t launch_h3_split_rows_long(const float* x, long ld, void* planes, float* scale, long R, int K, hipStream_t st) {
+    hipLaunchKernelGGL(h3_split_rows_long_kernel<0>, dim3((unsigned)R), dim3(256), 0, st, x, ld, (unsigned char*)planes, scale, K);
+    return hipGetLastError();
 }
 
 // K-major producer (diagnostics / stand-alone ops): fp32 [K][N] (pitch ld floats, N % 128 == 0) -> K-major planes

@@ -321,7 +321,7 @@ int tdx_eres2net_create(const void* blob, size_t blob_bytes, int device, tdx_ere
         size_t bi = 0;
         for (int s = 0; s < NSTAGE; ++s)
             for (int i = 0; i < kBlocks[s]; ++i, ++bi) {
-                if (s < 2) continue;
+                if (s < 1) continue;
                 BlockW& b = h->blocks[bi];
                 jobs.push_back(&b.conv1); if (b.has_sc) jobs.push_back(&b.sc);
                 for (int j = 0; j < SCALE; ++j) jobs.push_back(&b.convs[j]);
@@ -361,7 +361,7 @@ inline WsPlan ws_plan(const tdx_eres2net* h, int B, int F) {
     int s = 0, cnt = 0;
     for (const BlockW& b : h->blocks) {
         const size_t rows = (size_t)B * d.H[s + 1] * d.W[s + 1];
-        if (s >= 2) {      // planes of the x3 convolutions' inputs: block input, concatenated chain outputs, chain-conv input
+        if (s >= 1) {      // planes of the x3 convolutions' inputs: block input, concatenated chain outputs, chain-conv input
             const size_t rows_in = cnt == 0 ? (size_t)B * d.H[s] * d.W[s] : rows;
             mhx = std::max(mhx, rows_in * b.cin); mhc = std::max(mhc, rows * b.w4); mhi = std::max(mhi, rows * b.wpad);
         }

@@ -112,8 +112,8 @@ def cfg5_bench(args):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        hp.run(utts[:2], target, rank, world, 2 * world, with_asr=False)
+    for _ in range(max(args.warmup, 1)):        # same shapes as the timed steps: workspaces are sized on first use
+        hp.run(utts, target, rank, world, n_total, with_asr=False)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -185,6 +185,16 @@ int tdx_eres2net_forward(tdx_eres2net* h, const float* feat_dev, int B, int F, f
 int tdx_cosine_scores(const float* emb_dev, const float* ref_dev, int N, int D, float* scores_dev,
                       void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * N3   integrated loudness (ITU-R BS.1770-4) — replaces AudioProcessor.meter_loudness
+ *      AudioProcessor.py:1123-1127 (pyloudnorm.Meter(rate).integrated_loudness, third-party) on
+ *      device-resident clips: wav_dev [B,N] f32 mono -> lufs_dev [B] f64 (-inf for silence).
+ *      N must cover one 400 ms gating block (the reference raises ValueError otherwise).
+ * ---------------------------------------------------------------------------------- */
+size_t tdx_loudness_workspace_bytes(int B, long N, int rate);
+int tdx_loudness(const float* wav_dev, int B, long N, int rate, double* lufs_dev, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,8 @@ SIGNATURES = {
     "tdx_eres2net_flops": (C.c_double, [_vp, _i, _i]),
     "tdx_eres2net_forward": (_i, [_vp, _fp, _i, _i, _fp, _vp, _sz, _vp]),
     "tdx_cosine_scores": (_i, [_fp, _fp, _i, _i, _fp, _vp]),
+    "tdx_loudness_workspace_bytes": (_sz, [_i, C.c_long, _i]),
+    "tdx_loudness": (_i, [_fp, _i, C.c_long, _i, _vp, _vp, _sz, _vp]),
 }
 
 

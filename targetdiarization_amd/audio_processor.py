@@ -99,10 +99,10 @@ class AudioProcessor:
                     ends[-1] = start + n
         return list(zip(starts, ends))
 
-    def separate_windows(self, windows):
+    def separate_windows_device(self, windows):
         """Run the separator on a list of 1-D float32 windows; windows of equal length share one
         batched forward (bit-compatible with B=1: the model has no cross-sample op and the
-        reference never pads a batch, mossformer_block.py:485).  Returns list of [2,T] arrays."""
+        reference never pads a batch, mossformer_block.py:485).  Returns a list of [2,T] DEVICE tensors."""
         out = [None] * len(windows)
         by_len = {}
         for i, w in enumerate(windows):
@@ -112,10 +112,35 @@ class AudioProcessor:
             for c in range(0, len(idxs), 32):                # bound the workspace: <= 32 windows / launch
                 chunk = idxs[c:c + 32]
                 x = torch.from_numpy(np.stack([windows[i] for i in chunk]).astype(np.float32, copy=False)).to(dev)
-                y = self.separater(x).cpu().numpy()
+                y = self.separater(x)
                 for j, i in enumerate(chunk):
                     out[i] = y[j]
         return out
+
+    def separate_windows(self, windows):
+        """as above, host arrays"""
+        return [t.cpu().numpy() for t in self.separate_windows_device(windows)]
+
+    def louder_first(self, pairs):
+        """The reference's LUFS compare & swap (AudioProcessor.py:949-952) for a list of device stream pairs
+        [2,n]: one BS.1770 launch per distinct length (tdx_loudness), values rounded to 0.1 like meter_loudness
+        (:1123-1127).  Returns the list of (spk1, spk2) host arrays, louder stream first."""
+        from . import ops
+        swap = [False] * len(pairs)
+        by_len = {}
+        for i, p in enumerate(pairs):
+            by_len.setdefault(int(p.shape[1]), []).append(i)
+        for n, idxs in by_len.items():
+            if n < 6400:
+                continue                                      # shorter than one 400 ms gating block: the reference's ValueError path
+            l = ops.loudness(torch.cat([pairs[i] for i in idxs], 0), 16000).cpu().numpy().reshape(len(idxs), 2)
+            for k, i in enumerate(idxs):
+                swap[i] = round(float(l[k, 0]), 1) < round(float(l[k, 1]), 1)
+        res = []
+        for i, p in enumerate(pairs):
+            h = p.cpu().numpy()
+            res.append((h[1], h[0]) if swap[i] else (h[0], h[1]))
+        return res
 
     # AudioProcessor.py:885-956
     def separate_speaker(self, audio_data: np.ndarray, sampling_rate: int = 16000, low_gpu_ram: bool = False):
@@ -137,12 +162,6 @@ class AudioProcessor:
             return audio_data, audio_data
         plan = self.window_plan(audio_data.shape[0], window_size)
         wins = [audio_data[s:e].astype(np.float32, copy=True) for s, e in plan]
-        outs = self.separate_windows(wins)
-        spk1 = np.concatenate([o[0] for o in outs]).astype(np.float32)
-        spk2 = np.concatenate([o[1] for o in outs]).astype(np.float32)
-        try:                                                  # louder stream first, :949-952
-            if self.meter_loudness(spk1, 16000) < self.meter_loudness(spk2, 16000):
-                spk1, spk2 = spk2, spk1
-        except ValueError:
-            pass                                              # clip shorter than one 400 ms gating block
+        outs = self.separate_windows_device(wins)
+        spk1, spk2 = self.louder_first([torch.cat(outs, dim=1)])[0]      # louder stream first, :949-952 (metered on the device)
         return spk1, spk2

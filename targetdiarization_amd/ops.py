@@ -55,3 +55,20 @@ def cosine_scores(emb: torch.Tensor, ref: torch.Tensor) -> torch.Tensor:
     out = torch.empty(N, device=emb.device)
     _lib.check(_lib.lib().tdx_cosine_scores(emb.data_ptr(), ref.data_ptr(), N, D, out.data_ptr(), _st(emb)))
     return out
+
+
+def loudness(wav: torch.Tensor, rate: int = 16000) -> torch.Tensor:
+    """AudioProcessor.meter_loudness (AudioProcessor.py:1123-1127) for B device-resident mono clips [B,N]:
+    integrated loudness in LUFS as float64 [B] (unrounded; -inf for silence).  N >= 0.4 s."""
+    wav = wav.contiguous().float()
+    if wav.ndim == 1:
+        wav = wav[None]
+    B, N = wav.shape
+    l = _lib.lib()
+    nb = int(l.tdx_loudness_workspace_bytes(B, N, rate))
+    if nb == 0:
+        raise ValueError("Audio must have length greater than the block size.")
+    ws = torch.empty(nb, dtype=torch.uint8, device=wav.device)
+    out = torch.empty(B, dtype=torch.float64, device=wav.device)
+    _lib.check(l.tdx_loudness(wav.data_ptr(), B, N, rate, out.data_ptr(), ws.data_ptr(), nb, _st(wav)))
+    return out

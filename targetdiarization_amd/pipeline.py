@@ -71,20 +71,12 @@ class HotPath:
         for ui, (u, plan) in enumerate(zip(utts, plans)):
             for (s, e) in plan:
                 wins.append(u[s:e].astype(np.float32, copy=True)); owner.append(ui)
-        outs = self.ap.separate_windows(wins)
-        res = []
-        k = 0
-        for ui, plan in enumerate(plans):
-            a = np.concatenate([outs[k + j][0] for j in range(len(plan))])
-            b = np.concatenate([outs[k + j][1] for j in range(len(plan))])
+        outs = self.ap.separate_windows_device(wins)
+        pairs, k = [], 0
+        for plan in plans:
+            pairs.append(torch.cat(outs[k:k + len(plan)], dim=1))       # [2, n] on the device
             k += len(plan)
-            try:
-                if self.ap.meter_loudness(a, 16000) < self.ap.meter_loudness(b, 16000):
-                    a, b = b, a
-            except ValueError:
-                pass
-            res.append((a, b))
-        return res
+        return self.ap.louder_first(pairs)
 
     # ---- H2 -------------------------------------------------------------------------------
     def embed_streams(self, streams):

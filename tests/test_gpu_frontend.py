@@ -73,3 +73,29 @@ def test_block_stft_vs_torch_stft():
         # round trip through the device pair reproduces the dim_f-band-limited signal
         y2 = st.istft(spec)
         assert rel_l2(y2, yref) < 1e-5
+
+
+def test_loudness_vs_host_meter():
+    """tdx_loudness (BS.1770-4 on device, fp64) vs the host restatement targetdiarization_amd/loudness.py
+    (parity with pyloudnorm itself is unpinned: third-party, absent)."""
+    from targetdiarization_amd import ops
+    from targetdiarization_amd.loudness import integrated_loudness
+    g = np.random.default_rng(0)
+    for n in (6400, 6401, 16000, 30768, 138634, 160000):
+        t = np.arange(n) / 16000.0
+        clips = np.stack([
+            0.05 * g.standard_normal(n),
+            0.5 * np.sin(2 * np.pi * 997.0 * t),
+            0.2 * g.standard_normal(n) * (np.sin(2 * np.pi * 0.7 * t) > 0),      # gated bursts: the relative gate matters
+            np.zeros(n),                                                          # silence -> -inf
+            1e-4 * g.standard_normal(n),                                          # below the -70 LUFS absolute gate
+        ]).astype(np.float32)
+        out = ops.loudness(torch.from_numpy(clips).to(dev)).cpu().numpy()
+        for i in range(clips.shape[0]):
+            ref = integrated_loudness(clips[i], 16000)
+            if np.isinf(ref):
+                assert np.isinf(out[i]) and out[i] < 0, (n, i, out[i])
+            else:
+                assert abs(out[i] - ref) < 1e-6, (n, i, out[i], ref)
+    with pytest.raises(ValueError):
+        ops.loudness(torch.zeros(1, 6399, device=dev))

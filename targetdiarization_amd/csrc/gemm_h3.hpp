@@ -41,9 +41,10 @@
 //  * row-major planes (above): one operand row = one matrix row, k contiguous.  LDS image: row
 //    pitch 64 B (16 k x 2 planes x 2 B), the 16-B slot q of row r stored at slot q ^ ((r>>2)&3),
 //    read with ds_read_b128 (conflict-free over its four 16-lane groups).
-//  * K-major planes ("TR"): the matrix is stored [k][n/128][2 planes][128] f16 — k is the
-//    slow index, as activations indexed by token are — with ONE scale for the whole matrix
-//    (a static bound, see mf2.hip).  LDS image per k row: 1 KiB = [blk 0: hi 256 B | lo 256 B]
+//  * K-major planes ("TR"): the matrix is stored [k][n/32][2 planes][32] f16 — k is the
+//    slow index, as activations indexed by token are; hi and lo of 32 columns share one 128-B
+//    line, so an element-wise consumer (the attention gate) reads full lines — with ONE scale for
+//    the whole matrix (a static bound, see mf2.hip).  LDS image per k row: 1 KiB = [blk 0: hi 256 B | lo 256 B]
 //    [blk 1: ...], the 64-B windows of a 256-B plane row permuted by window ^ (k&3); fragments
 //    are gathered with ds_read_b64_tr_b16 (4 k x 16 n per 16-lane group, two per fragment),
 //    conflict-free per 32-lane half.
@@ -303,7 +304,10 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
                 const int blk = min(m0 / 128 + (lane >> 5), (g.M - 1) / 128);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    gp[j] = Ag + (long)((wave & 3) * 4 + j) * sg.lda + blk * 512 + ((lane >> 4) & 1) * 256 + (((lane & 15) ^ (j << 2)) << 4);
+                    {
+                    const int ch = (lane & 15) ^ (j << 2);       // logical 16-B chunk (8 columns) of the 128-column block
+                    gp[j] = Ag + (long)((wave & 3) * 4 + j) * sg.lda + blk * 512 + (ch >> 2) * 128 + ((lane >> 4) & 1) * 64 + (ch & 3) * 16;
+                }
             }
         } else {
             const unsigned char* Bg = sg.B + (long)z1 * sg.strideB + (long)z2 * sg.strideB2;
@@ -320,7 +324,10 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
                 const int ncol = PAIRED ? ((lane >> 5) ? g.pair_off + n0 : n0) : min(n0 + 128 * (lane >> 5), g.N - 128);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    gp[j] = Bg + (long)((wave & 3) * 4 + j) * sg.ldb + (ncol / 128) * 512 + ((lane >> 4) & 1) * 256 + (((lane & 15) ^ (j << 2)) << 4);
+                    {
+                    const int ch = (lane & 15) ^ (j << 2);
+                    gp[j] = Bg + (long)((wave & 3) * 4 + j) * sg.ldb + (ncol / 128) * 512 + (ch >> 2) * 128 + ((lane >> 4) & 1) * 64 + (ch & 3) * 16;
+                }
             }
         }
     };
@@ -741,7 +748,7 @@ inline hipError_t launch_h3_split_rows_long(const float* x, long ld, void* plane
 }
 
 // K-major producer (diagnostics / stand-alone ops): fp32 [K][N] (pitch ld floats, N % 128 == 0) -> K-major planes
-// [k][N/128][2][128] with one scale: s (a power of two chosen by the caller: max|x|*s < 65504), or, when mx is
+// [k][N/32][2][32] with one scale: s (a power of two chosen by the caller: max|x|*s < 65504), or, when mx is
 // given, the exact exponent-aligned scale of the float whose bits are mx[0] (its inverse is written to inv[0]).
 // With Sp > 0 the k rows are [b][Sp] and row (b, t) reads source row b*S + t, zero for t >= S (group padding).
 template <int UNUSED = 0>
@@ -771,9 +778,9 @@ __global__ __launch_bounds__(256) void h3_split_kmajor_kernel(const float* __res
         const _Float16 t = (_Float16)xs;
         hi[j] = t; lo[j] = (_Float16)(xs - (float)t);
     }
-    unsigned char* dst = planes + k * (4L * N) + (n / 128) * 512 + (n % 128) * 2;
+    unsigned char* dst = planes + k * (4L * N) + (n >> 5) * 128 + ((n & 31) >> 3) * 16;
     *reinterpret_cast<f16x8*>(dst) = hi;
-    *reinterpret_cast<f16x8*>(dst + 256) = lo;
+    *reinterpret_cast<f16x8*>(dst + 64) = lo;
 }
 
 // max |x| over n floats as float bits (atomicMax; mx zeroed by the caller)

@@ -73,6 +73,34 @@ struct EpiAttnGate { // o = (att_u*v)*sigmoid(att_v*u)                       mos
         }
     }
 };
+struct EpiAttnGatePl { // the same gate with v, u read back from the K-major split-f16 planes: v = (hi + lo) * inv.  hi and lo of 32
+    // columns share one 128-B line; lanes 2j / 2j+1 (adjacent columns) share the loads: the even lane fetches the 4-byte
+    // (c, c+1) word of hi, the odd lane that of lo, for v and for u — two loads per output element and the same lines as an
+    // fp32 copy of v|u, which then need not be written (8 KB per token less in conv17<4>).  aux() returns the RAW words (the
+    // kernel issues it one half block ahead of the stores: anything that consumed the loads there would wait for them
+    // there); the lane swap (DPP quad_perm [1,0,3,2]) and the unpacking happen in store2().
+    const unsigned char* vuP; const float* inv; float* o; int G; int S; int Sp; int E;
+    __device__ EpiNone col(int, int) const { return EpiNone{}; }
+    __device__ long row(int z, int m) const { const int b = z / G, s = (z % G) * 256 + m; return s < S ? (long)b * S + s : -1L; }
+    __device__ int2 aux(int z, int m, int c, long) const {
+        const int b = z / G, s = min((z % G) * 256 + m, S - 1);
+        const int c2 = c & ~1;
+        const unsigned char* p = vuP + ((long)b * Sp + s) * (8L * E) + (c2 >> 5) * 128 + (c2 & 31) * 2 + (c & 1) * 64;
+        return make_int2(*reinterpret_cast<const int*>(p), *reinterpret_cast<const int*>(p + 4L * E));
+    }
+    __device__ void store2(int, int, int c, float av, float au, long rw, EpiNone, int2 w) const {
+        const int odd = c & 1;
+        const int ov = __builtin_amdgcn_mov_dpp(w.x, 0xB1, 0xF, 0xF, true), ou = __builtin_amdgcn_mov_dpp(w.y, 0xB1, 0xF, 0xF, true);
+        if (rw < 0) return;
+        const unsigned hv = odd ? ov : w.x, lv = odd ? w.x : ov, hu = odd ? ou : w.y, lu = odd ? w.y : ou;
+        const int sh = odd * 16;
+        union { unsigned short u; _Float16 h; } a, bq, cq, d;
+        a.u = (unsigned short)(hv >> sh); bq.u = (unsigned short)(lv >> sh); cq.u = (unsigned short)(hu >> sh); d.u = (unsigned short)(lu >> sh);
+        const float k = inv[0];
+        const float v = ((float)a.h + (float)bq.h) * k, u = ((float)cq.h + (float)d.h) * k;
+        o[rw * E + c] = (au * v) * sigmoidf_acc(av * u);
+    }
+};
 struct EpiBiasPrelu { // prelu_scalar(acc + b[n])                            mossformer_block.py:405-408
     const float* b; const float* a; float* out; long ld;
     __device__ Col2 col(int, int n) const { return Col2{b[n], a[0]}; }
@@ -341,7 +369,7 @@ int attention_core(const float* qk4, const float* vu, int B, int S, int E, int s
 // The same attention on the split-f16 x3 core (gemm_h3.hpp), E = 1024:
 //   qkP : the four heads as planes in [4][B][Sp] x 512 B slots (conv17 MODE 3): quad_q, lin_q, quad_k row-major
 //         with row scales qks[3][B*Sp]; lin_k K-major with the static scale st[1]
-//   vuP : K-major planes [B][Sp][16][2][128] of v|u with the static scale st[0] (pad rows zero); vu: fp32 (gate)
+//   vuP : K-major planes [B][Sp][64][2][32] of v|u with the static scale st[0] (pad rows zero); vu: fp32 (gate)
 int attention_core_h3(const unsigned char* qkP, const float* qks, const unsigned char* vuP, const float* vu, const float* st,
                       int B, int S, int E, int splits, int kchunk, float* Abuf, unsigned char* AbufP, float* Asc, float* slab, float* kvu,
                       unsigned char* KvuP, float* kvus, float* o, float* att_v, float* att_u, hipStream_t st_) {
@@ -394,7 +422,12 @@ int attention_core_h3(const unsigned char* qkP, const float* qks, const unsigned
         g.seg[1].strideB = (long)QK * 4 * 2 * E; g.seg[1].strideB2 = 0;
         g.seg[1].strideSB = 1; g.seg[1].strideSB2 = 0;
         g.nseg = 2; g.M = 256; g.N = E; g.pair_off = E;
-        EpiAttnGate e{vu, o, att_v, att_u, G, S, E};      // (reading the gate operands back from the planes instead of fp32 v|u measured 25 % slower)
+        if (o && !vu) {       // the model: gate operands from the planes (no fp32 copy of v|u exists)
+            if (tdx::launch_gemm_h3x<false, true, true, true>(g, B * G, EpiAttnGatePl{vuP, st, o, G, S, Sp, E}, st_) != hipSuccess)
+                return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+            return TDX_OK;
+        }
+        EpiAttnGate e{vu, o, att_v, att_u, G, S, E};
         if (tdx::launch_gemm_h3x<false, true, true, true>(g, B * G, e, st_) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
     }
     return TDX_OK;
@@ -804,16 +837,16 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
         }
         {
             Conv17Args a{};
-            a.in = hid; a.ld_in = HQ; a.col0 = 0; a.wT = w.cw_h; a.C = HID; a.out = vu; a.ld_out = HID; a.S = S; a.Sp = Sp;
+            a.in = hid; a.ld_in = HQ; a.col0 = 0; a.wT = w.cw_h; a.C = HID; a.out = nullptr; a.ld_out = HID; a.S = S; a.Sp = Sp;
             a.hp = vuP; a.sv = w.sv_vu;
-            TRY(launch_conv17<4>(a, B, st));          // v|u in fp32 (gate operands) and as K-major planes (GEMM operands)
+            TRY(launch_conv17<4>(a, B, st));          // v|u as K-major planes only: GEMM operands and (read back in the epilogue) gate operands
             Conv17Args q{};
             q.in = hid; q.ld_in = HQ; q.col0 = HID; q.wT = w.cw_qk; q.C = QK; q.S = S; q.Sp = Sp; q.gamma = w.gamma; q.beta = w.beta;
             q.rot_cos = rc; q.rot_sin = rsn; q.head_stride = (long)B * Sp * QK;
             q.hp = (unsigned char*)qk4; q.hs = qks; q.sv = w.sv_lk;
             TRY(launch_conv17<3>(q, B, st));          // the four heads as planes
         }
-        TRY(attention_core_h3((const unsigned char*)qk4, qks, vuP, vu, w.st, B, S, 1024, P.splits, P.kchunk, Abuf, AbufP, Asc, slab, kvu, KvuP,
+        TRY(attention_core_h3((const unsigned char*)qk4, qks, vuP, nullptr, w.st, B, S, 1024, P.splits, P.kchunk, Abuf, AbufP, Asc, slab, kvu, KvuP,
                               kvus, o, nullptr, nullptr, st));
         hipLaunchKernelGGL((rowscale_split_kernel<1024, false>), rows4(M), dim3(256), 0, st, o, rs, hp, hs, M, S);
         LAUNCH_CHECK();

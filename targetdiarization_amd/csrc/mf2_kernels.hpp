@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void fsmn_tail_kernel(const float* __restrict_
 
 // x3 path: kvu[b][d][ch] = (sum_sp slab[b][sp][d][ch]) / S in fp32, and per block the max |value| (bmax[b][block];
 // no atomics: 1024 waves hammering one word cost 250 us).  Then kvu_planes_kernel reduces the block maxima and
-// re-writes kvu as K-major planes KvuP[b][d][16][2][128] with one exact power-of-two scale per sample (the B
+// re-writes kvu as K-major planes KvuP[b][d][64][2][32] with one exact power-of-two scale per sample (the B
 // operand of the attention GEMM's linear segment).
 __global__ __launch_bounds__(256) void kvu_reduce_t_kernel(const float* __restrict__ slab, float* __restrict__ kvu, int splits, long per,
                                                             float S, float* __restrict__ bmax) {
@@ -467,9 +467,9 @@ __global__ __launch_bounds__(256) void kvu_planes_kernel(const float* __restrict
         const _Float16 t = (_Float16)xs;
         hi[j] = t; lo[j] = (_Float16)(xs - (float)t);
     }
-    unsigned char* dst = planes + ((long)b * 128 + d) * (4L * E2) + (ch >> 7) * 512 + (ch & 127) * 2;
+    unsigned char* dst = planes + ((long)b * 128 + d) * (4L * E2) + (ch >> 5) * 128 + ((ch & 31) >> 3) * 16;
     *reinterpret_cast<f16x8*>(dst) = hi;
-    *reinterpret_cast<f16x8*>(dst + 256) = lo;
+    *reinterpret_cast<f16x8*>(dst + 64) = lo;
     if (i == 0) scale[b] = inv;
 }
 

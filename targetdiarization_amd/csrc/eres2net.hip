@@ -151,6 +151,87 @@ struct EpiAffGate {     // att = 1 + tanh(v+b); out = x*att + y*(2-att), columns
     }
 };
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Res2Net chain convolution of stage 1 (3x3, 24 -> 24 channels, stride 1) as an LDS-tiled DIRECT convolution.
+// As an implicit GEMM these launches re-read every input pixel nine times from L2 for 24 output columns of a
+// 128-wide tile; here a block stages the (8+2) x (32+2) pixel patch (24 channels, pixel pitch 28 floats:
+// conflict-free ds_read_b128 over consecutive pixels) and the 9 x 24 x 32 weights once and feeds
+// v_mfma_f32_32x32x2_f32 from LDS: wave w owns output rows 2w, 2w+1 of the tile (one 32-pixel row = one MFMA row
+// tile), 216 MFMAs per wave.  Epilogue = EpiChain.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int DC_TH = 8, DC_TW = 32, DC_C = 24, DC_PP = 28;        // tile rows / cols, channels, LDS pixel pitch (floats)
+struct DirectConvArgs {
+    const float* in; long ldin;          // NHWC input [B*H*W][ldin], channels 0..23
+    const float* w;                      // folded weights [>=32 rows n][9 taps][32] (rows >= 24 zero), bias b[n]
+    const float* b;
+    float* cat; long ldcat; int coff;    // sp -> cat[m*ldcat + coff + n], n < 24
+    const float* o1; long ldo1; int next_off; float* spin;      // spin (or null): spin[m*32 + n] = n < 24 ? sp + o1[m*ldo1 + next_off + n] : 0
+    int H, W;
+};
+__global__ __launch_bounds__(256) void chain_conv24_kernel(DirectConvArgs a) {
+    __shared__ __attribute__((aligned(16))) float patch[(DC_TH + 2) * (DC_TW + 2) * DC_PP];
+    __shared__ __attribute__((aligned(16))) float wl[9 * DC_C * DC_C];          // [tap][k][n < 24]  (58.8 KB of LDS in all: two blocks per CU)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int x0 = blockIdx.x * DC_TW, y0 = blockIdx.y * DC_TH, b = blockIdx.z;
+    // ---- stage the input patch (zero outside the image) and the weights
+    for (int t = tid; t < (DC_TH + 2) * (DC_TW + 2) * (DC_C / 4); t += 256) {
+        const int p = t / (DC_C / 4), q = t - p * (DC_C / 4);
+        const int py = p / (DC_TW + 2), px = p - py * (DC_TW + 2);
+        const int iy = y0 + py - 1, ix = x0 + px - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *reinterpret_cast<const float4*>(a.in + (((long)b * a.H + iy) * a.W + ix) * a.ldin + 4 * q);
+        *reinterpret_cast<float4*>(patch + p * DC_PP + 4 * q) = v;
+    }
+    for (int t = tid; t < 9 * DC_C * DC_C; t += 256) {
+        const int n = t % DC_C, k = (t / DC_C) % DC_C, tap = t / (DC_C * DC_C);
+        wl[t] = a.w[((long)n * 9 + tap) * 32 + k];
+    }
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap - dy * 3;              // patch offsets (halo of one pixel already included)
+#pragma unroll
+        for (int kc = 0; kc < 3; ++kc) {
+            const int k0 = 8 * kc + 4 * h;
+            float bv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = wl[(tap * DC_C + k0 + j) * DC_C + min(l31, DC_C - 1)];      // columns >= 24 are never stored
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(patch + ((2 * wave + r + dy) * (DC_TW + 2) + l31 + dx) * DC_PP + k0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[r], 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue (EpiChain): D col = l31 (output channel), row = (r&3) + 8*(r>>2) + 4*h (pixel of the row)
+    const float bias = l31 < DC_C ? a.b[l31] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int y = y0 + 2 * wave + r;
+        if (y >= a.H) continue;
+        float nx[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int x = min(x0 + (i & 3) + 8 * (i >> 2) + 4 * h, a.W - 1);
+            nx[i] = (a.spin && l31 < DC_C) ? a.o1[(((long)b * a.H + y) * a.W + x) * a.ldo1 + a.next_off + l31] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int x = x0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (x >= a.W) continue;
+            const long m = ((long)b * a.H + y) * a.W + x;
+            const float sp = relu20(acc[r][i] + bias);
+            if (l31 < DC_C) a.cat[m * a.ldcat + a.coff + l31] = sp;
+            if (a.spin) a.spin[m * 32 + l31] = l31 < DC_C ? sp + nx[i] : 0.f;
+        }
+    }
+}
+
 struct ConvW {
     size_t w, b; int N, Npad, cin, cinp, taps;
     const unsigned char* hp = nullptr; const float* hs = nullptr;     // split-f16 planes [Npad][taps*cinp] + row scales (x3 core), if made
@@ -462,7 +543,12 @@ int tdx_eres2net_forward(tdx_eres2net* h, const float* feat, int B, int F, float
             const bool plain_next = (j + 1 < SCALE) && !b.is_aff;
             EpiChain e{h->dev + b.convs[j].b, cat, b.w4, j * b.width, b.width, b.wpad, o1, b.w4, (j + 1) * b.width,
                        plain_next ? spin[(j + 1) & 1] : nullptr};
-            if (x3) {     // chain input = sum of two ReLU20 outputs or an AFF blend of them (<= 40): static scale 2^9
+            if (b.width == DC_C && b.wpad == 32 && !b.is_aff) {     // stage 1: LDS-tiled direct convolution
+                DirectConvArgs da{in, ldin, h->dev + b.convs[j].w, h->dev + b.convs[j].b, cat, b.w4, j * b.width, o1, b.w4, (j + 1) * b.width,
+                                  plain_next ? spin[(j + 1) & 1] : nullptr, Ho, Wo};
+                hipLaunchKernelGGL(chain_conv24_kernel, dim3((Wo + DC_TW - 1) / DC_TW, (Ho + DC_TH - 1) / DC_TH, B), dim3(256), 0, st, da);
+                LAUNCH_CHECK();
+            } else if (x3) {     // chain input = sum of two ReLU20 outputs or an AFF blend of them (<= 40): static scale 2^9
                 if (tdx::launch_h3_split_rows_static(in, ldin, hin, M, b.wpad, 512.0f, st) != hipSuccess)
                     return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
                 TRY(conv_gemm_h3(hin, inv40, zero_row, b.convs[j], B, Ho, Wo, Ho, Wo, 1, e, st));

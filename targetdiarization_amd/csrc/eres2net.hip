@@ -163,7 +163,7 @@ struct EpiAffGate {     // att = 1 + tanh(v+b); out = x*att + y*(2-att), columns
 constexpr int DC_TH = 8, DC_TW = 32, DC_C = 24, DC_PP = 28;        // tile rows / cols, channels, LDS pixel pitch (floats)
 struct DirectConvArgs {
     const float* in; long ldin;          // NHWC input [B*H*W][ldin], channels 0..23
-    const float* w;                      // folded weights [>=32 rows n][9 taps][32] (rows >= 24 zero), bias b[n]
+    const float* w;                      // folded weights as [9 taps][24 k][24 n] (ConvW::wd), bias b[n]
     const float* b;
     float* cat; long ldcat; int coff;    // sp -> cat[m*ldcat + coff + n], n < 24
     const float* o1; long ldo1; int next_off; float* spin;      // spin (or null): spin[m*32 + n] = n < 24 ? sp + o1[m*ldo1 + next_off + n] : 0
@@ -183,10 +183,7 @@ __global__ __launch_bounds__(256) void chain_conv24_kernel(DirectConvArgs a) {
         if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *reinterpret_cast<const float4*>(a.in + (((long)b * a.H + iy) * a.W + ix) * a.ldin + 4 * q);
         *reinterpret_cast<float4*>(patch + p * DC_PP + 4 * q) = v;
     }
-    for (int t = tid; t < 9 * DC_C * DC_C; t += 256) {
-        const int n = t % DC_C, k = (t / DC_C) % DC_C, tap = t / (DC_C * DC_C);
-        wl[t] = a.w[((long)n * 9 + tap) * 32 + k];
-    }
+    for (int t = tid; t < 9 * DC_C * DC_C / 4; t += 256) *reinterpret_cast<float4*>(wl + 4 * t) = *reinterpret_cast<const float4*>(a.w + 4 * t);
     __syncthreads();
     f32x16 acc[2];
 #pragma unroll
@@ -234,6 +231,7 @@ __global__ __launch_bounds__(256) void chain_conv24_kernel(DirectConvArgs a) {
 
 struct ConvW {
     size_t w, b; int N, Npad, cin, cinp, taps;
+    size_t wd = 0;       // 24 -> 24 3x3 convolutions: the weights again as [tap][k][n] (what chain_conv24_kernel stages into LDS)
     const unsigned char* hp = nullptr; const float* hs = nullptr;     // split-f16 planes [Npad][taps*cinp] + row scales (x3 core), if made
 };
 struct AffW { ConvW c0, c3; int C, inter, ipad; };
@@ -336,6 +334,11 @@ int tdx_eres2net_create(const void* blob, size_t blob_bytes, int device, tdx_ere
             for (int c = 0; c < cin; ++c)
                 for (int t = 0; t < taps; ++t)
                     host[cw.w + ((size_t)n * taps + t) * cw.cinp + c] = (float)((double)W[((size_t)n * cin + c) * taps + t] * sc);
+        }
+        if (N == 24 && cin == 24 && taps == 9) {
+            cw.wd = host.size(); host.resize(host.size() + al(9 * 24 * 24), 0.f);
+            for (int t = 0; t < 9; ++t) for (int c = 0; c < 24; ++c) for (int n = 0; n < 24; ++n)
+                host[cw.wd + ((size_t)t * 24 + c) * 24 + n] = host[cw.w + ((size_t)n * 9 + t) * cw.cinp + c];
         }
         return cw;
     };
@@ -544,7 +547,7 @@ int tdx_eres2net_forward(tdx_eres2net* h, const float* feat, int B, int F, float
             EpiChain e{h->dev + b.convs[j].b, cat, b.w4, j * b.width, b.width, b.wpad, o1, b.w4, (j + 1) * b.width,
                        plain_next ? spin[(j + 1) & 1] : nullptr};
             if (b.width == DC_C && b.wpad == 32 && !b.is_aff) {     // stage 1: LDS-tiled direct convolution
-                DirectConvArgs da{in, ldin, h->dev + b.convs[j].w, h->dev + b.convs[j].b, cat, b.w4, j * b.width, o1, b.w4, (j + 1) * b.width,
+                DirectConvArgs da{in, ldin, h->dev + b.convs[j].wd, h->dev + b.convs[j].b, cat, b.w4, j * b.width, o1, b.w4, (j + 1) * b.width,
                                   plain_next ? spin[(j + 1) & 1] : nullptr, Ho, Wo};
                 hipLaunchKernelGGL(chain_conv24_kernel, dim3((Wo + DC_TW - 1) / DC_TW, (Ho + DC_TH - 1) / DC_TH, B), dim3(256), 0, st, da);
                 LAUNCH_CHECK();

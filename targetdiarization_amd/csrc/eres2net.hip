@@ -103,24 +103,24 @@ struct EpiRelu20 {      // clamp(v + b, 0, 20), columns < nreal
     const float* b; float* out; long ld; int nreal;
     __device__ float col(int, int n) const { return b[n]; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
-    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { if (n < nreal) out[(long)m * ld + n] = relu20(v + c); }
+    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { if (n < nreal) out[(long)m * (int)ld + n] = relu20(v + c); }
 };
 struct EpiBiasG {       // v + b, columns < nreal
     const float* b; float* out; long ld; int nreal;
     __device__ float col(int, int n) const { return b ? b[n] : 0.f; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
-    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { if (n < nreal) out[(long)m * ld + n] = v + c; }
+    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { if (n < nreal) out[(long)m * (int)ld + n] = v + c; }
 };
 struct EpiChain {       // Res2Net chain: sp = relu20(v+b) -> cat[:, coff+n]; next input sp + spx[i+1] -> spin
     const float* b; float* cat; long ldcat; int coff; int width; int wpad;
     const float* o1; long ldo1; int next_off; float* spin;      // spin == nullptr: no plain-add successor
     __device__ float col(int, int n) const { return b[n]; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
-    __device__ float aux(int, int m, int n, EpiNone) const { return (spin && n < width) ? o1[(long)m * ldo1 + next_off + n] : 0.f; }
+    __device__ float aux(int, int m, int n, EpiNone) const { return (spin && n < width) ? o1[(long)m * (int)ldo1 + next_off + n] : 0.f; }
     __device__ void store(int, int m, int n, float v, EpiNone, float c, float nxt) const {
         if (n >= wpad) return;
         const float sp = relu20(v + c);
-        if (n < width) cat[(long)m * ldcat + coff + n] = sp;
+        if (n < width) cat[(long)m * (int)ldcat + coff + n] = sp;
         if (spin) spin[(long)m * wpad + n] = n < width ? sp + nxt : 0.f;
     }
 };
@@ -128,8 +128,8 @@ struct EpiConv3 {       // relu20(v + b + residual)
     const float* b; const float* res; float* out; long ld;
     __device__ float col(int, int n) const { return b[n]; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
-    __device__ float aux(int, int m, int n, EpiNone) const { return res[(long)m * ld + n]; }
-    __device__ void store(int, int m, int n, float v, EpiNone, float c, float r) const { out[(long)m * ld + n] = relu20(v + c + r); }
+    __device__ float aux(int, int m, int n, EpiNone) const { return res[(long)m * (int)ld + n]; }
+    __device__ void store(int, int m, int n, float v, EpiNone, float c, float r) const { out[(long)m * (int)ld + n] = relu20(v + c + r); }
 };
 struct EpiAffSilu {     // t = silu(v + b), columns < ipad
     const float* b; float* t; int ipad;
@@ -142,12 +142,12 @@ struct EpiAffGate {     // att = 1 + tanh(v+b); out = x*att + y*(2-att), columns
     __device__ float col(int, int n) const { return b[n]; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
     __device__ float2 aux(int, int m, int n, EpiNone) const {
-        return n < C ? make_float2(x[(long)m * ldx + n], y[(long)m * ldy + n]) : make_float2(0.f, 0.f);
+        return n < C ? make_float2(x[(long)m * (int)ldx + n], y[(long)m * (int)ldy + n]) : make_float2(0.f, 0.f);
     }
     __device__ void store(int, int m, int n, float v, EpiNone, float c, float2 xy) const {
         if (n >= C) return;
         const float att = 1.0f + tanhf(v + c);
-        out[(long)m * ldo + n] = xy.x * att + xy.y * (2.0f - att);
+        out[(long)m * (int)ldo + n] = xy.x * att + xy.y * (2.0f - att);
     }
 };
 

@@ -225,6 +225,13 @@ __device__ __forceinline__ void h3_stage_dma_only(const unsigned char* const (&g
 // A_TR / B_TR: operand in K-major planes.  TWOSEG: two K segments (same operand formats, their own
 // pointers and scales).  VARIANT != 0: timing-only diagnostics (wrong results): 1 no LDS-DMA in
 // the loop, 2 no fragment reads, 3 neither, 4 no barrier.
+// optional functor member full(z, m0): all 256 rows of the tile are real rows (row() >= 0 for the functors whose row() marks
+// padding with -1) — lets the epilogue take its branch-free path
+template <class E, class = void> struct epi_has_full { static constexpr bool value = false; };
+template <class E> struct epi_has_full<E, decltype((void)&E::full, void())> { static constexpr bool value = true; };
+template <class T> __device__ __forceinline__ void h3_assume_row(const T&) {}
+__device__ __forceinline__ void h3_assume_row(long rw) { __builtin_assume(rw >= 0); }
+
 template <bool A_TR, bool B_TR, bool PAIRED, bool TWOSEG, class Epi, int VARIANT = 0, bool A_CONV = false>
 __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi epi) {
     static_assert(!A_CONV || (!A_TR && !TWOSEG), "A_CONV: row-major A planes, one weight segment");
@@ -349,6 +356,21 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
         }
     };
 
+    // the epilogue's row scales wait in LDS behind the ring (and the TWOSEG row factors): loaded here, ahead of the
+    // prologue's DMA, they cost the epilogue a ds_read instead of one exposed global-load round trip per row block
+    const H3Seg& sl = g.seg[TWOSEG ? 1 : 0];
+    const int zl1 = z / sl.zdiv, zl2 = z - zl1 * sl.zdiv;
+    using RowT = decltype(epi.row(0, 0));
+    constexpr bool HAS_ROW = !std::is_empty<RowT>::value;
+    float* sal = reinterpret_cast<float*>(lds + H3_LDS + 1024);
+    RowT* rwl = reinterpret_cast<RowT*>(lds + H3_LDS + 2048);
+    float sa_own = 0.f;
+    RowT rw_own{};
+    if (tid < 256) {
+        sa_own = (sl.sa + (long)zl1 * sl.strideSA + (long)zl2 * sl.strideSA2)[(long)min(m0 + tid, g.M - 1) * sl.sa_mul];
+        if constexpr (HAS_ROW) rw_own = epi.row(z, min(m0 + tid, g.M - 1));
+    }
+
     const H3Seg& sg0 = g.seg[0];
     const int zz2 = z % sg0.zdiv;
     const int nkt0 = (sg0.kchunk ? max(0, min(sg0.K, sg0.ktotal - zz2 * sg0.kchunk)) : sg0.K) / H3_BK;
@@ -377,6 +399,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
 #pragma unroll
                 for (int j = 0; j < 4; ++j) h3_glds16(gp[j] + p * gstep, lds + p * H3_STAGE + sdst + j * 1024);
             }
+        if (tid < 256) { sal[tid] = sa_own; if constexpr (HAS_ROW) rwl[tid] = rw_own; }
         if (nkt0 >= 4) H3_WAIT_VM(12); else if (nkt0 == 3) H3_WAIT_VM(8); else if (nkt0 == 2) H3_WAIT_VM(4); else H3_WAIT_VM(0);
         H3_BARRIER();
         f16x8 ah[4], al[4], bh[2], bl[2];
@@ -460,107 +483,145 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
         else { if (stB) H3_RUN(false, 1) else H3_RUN(false, 0) }
 #undef H3_RUN
 #undef H3_STEADY
+    } else {
+        if (tid < 256) { sal[tid] = sa_own; if constexpr (HAS_ROW) rwl[tid] = rw_own; }
+        __syncthreads();
     }
 
-    // ---- epilogue: D col = l31, row = (r&3) + 8*(r>>2) + 4*h; scales of the LAST segment
-    const H3Seg& sl = g.seg[TWOSEG ? 1 : 0];
-    const int zl1 = z / sl.zdiv, zl2 = z - zl1 * sl.zdiv;
-    const float* sa = sl.sa + (long)zl1 * sl.strideSA + (long)zl2 * sl.strideSA2;
+    // ---- epilogue: D col = l31, row = (r&3) + 8*(r>>2) + 4*h; scales of the LAST segment.
+    // vmcnt retires in order and counts stores: any wait on a load issued after a store waits for that store's round
+    // trip (~130 ns on an idle chip).  So (i) a tile whose 256 rows all exist takes a branch-free path — per-row
+    // `if (m < M)` blocks make the compiler's waitcnt pass re-wait vmcnt(0) at every block entry, i.e. one store round
+    // trip per store: 17 us per tile; (ii) row scales and the functor's row() values come from LDS (staged before the
+    // prologue); (iii) column constants are fetched before the first store and aux() operands half a row block ahead.
+    if constexpr (VARIANT == 8) {       // (timing: no epilogue)
+        float x = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x += acc[0][0][r] + acc[1][1][r] + acc[2][0][r] + acc[3][1][r];
+        if (x != 123.456f) return;
+    }
     const float* sb = sl.sb + (long)zl1 * sl.strideSB + (long)zl2 * sl.strideSB2;
-    const int sam = sl.sa_mul, sbm = sl.sb_mul;
-    if constexpr (PAIRED) {
-        const int c = n0 + wn * 32 + l31;
-        const auto cc = epi.col(z, c);
-        const float sc0 = sb[(long)c * sbm], sc1 = sb[(long)(g.pair_off + c) * sbm];
-        if constexpr (epi_has_aux<Epi>::value) {
-            // the epilogue's own loads (gate operands ...) are cold HBM reads: those of row block tm+1 are issued
-            // before the stores of row block tm, so that only the first block's latency is exposed
-            // (half row blocks of 8 accumulator registers: two sets of 8 rows fit beside the 128 accumulators)
-            decltype(epi.row(0, 0)) rw[2][8];
-            float sr[2][8];
-            decltype(epi.aux(0, 0, 0, rw[0][0])) ax[2][8];
+    const int sbm = sl.sb_mul;
+    const int lrow = wm * 128 + 4 * h;                      // this lane's first row inside the tile
+    auto row_of = [&](int lr) -> RowT { if constexpr (HAS_ROW) return rwl[lr]; else return RowT{}; };
+    auto epilogue = [&](auto tag) {
+        constexpr bool CHECK = decltype(tag)::value;
+        auto rowm = [&](int lr) { return CHECK ? min(m0 + lr, g.M - 1) : m0 + lr; };
+        if constexpr (PAIRED) {
+            const int c = n0 + wn * 32 + l31;
+            const auto cc = epi.col(z, c);
+            const float sc0 = sb[(long)c * sbm], sc1 = sb[(long)(g.pair_off + c) * sbm];
+            if constexpr (epi_has_aux<Epi>::value) {
+                RowT rw[2][8];
+                float sr[2][8];
+                decltype(epi.aux(0, 0, 0, rw[0][0])) ax[2][8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int m = min(m0 + wm * 128 + (r & 3) + 8 * (r >> 2) + 4 * h, g.M - 1);
-                rw[0][r] = epi.row(z, m);
-                sr[0][r] = sa[(long)m * sam];
-                ax[0][r] = epi.aux(z, m, c, rw[0][r]);
-            }
-#pragma unroll
-            for (int hb = 0; hb < 8; ++hb) {
-                if (hb < 7) {
-#pragma unroll
-                    for (int r8 = 0; r8 < 8; ++r8) {
-                        const int r = ((hb + 1) & 1) * 8 + r8;
-                        const int m = min(m0 + wm * 128 + ((hb + 1) >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, g.M - 1);
-                        rw[(hb + 1) & 1][r8] = epi.row(z, m);
-                        sr[(hb + 1) & 1][r8] = sa[(long)m * sam];
-                        ax[(hb + 1) & 1][r8] = epi.aux(z, m, c, rw[(hb + 1) & 1][r8]);
-                    }
+                for (int r = 0; r < 8; ++r) {
+                    const int lr = lrow + (r & 3) + 8 * (r >> 2);
+                    rw[0][r] = row_of(lr);
+                    sr[0][r] = sal[lr];
+                    ax[0][r] = epi.aux(z, rowm(lr), c, rw[0][r]);
                 }
 #pragma unroll
-                for (int r8 = 0; r8 < 8; ++r8) {
-                    const int tm = hb >> 1, r = (hb & 1) * 8 + r8;
-                    const int m = m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (m < g.M)
-                        epi.store2(z, m, c, acc[tm][0][r] * (sr[hb & 1][r8] * sc0), acc[tm][1][r] * (sr[hb & 1][r8] * sc1), rw[hb & 1][r8], cc,
-                                   ax[hb & 1][r8]);
+                for (int hb = 0; hb < 8; ++hb) {
+                    if (hb < 7) {
+#pragma unroll
+                        for (int r8 = 0; r8 < 8; ++r8) {
+                            const int r = ((hb + 1) & 1) * 8 + r8;
+                            const int lr = lrow + ((hb + 1) >> 1) * 32 + (r & 3) + 8 * (r >> 2);
+                            rw[(hb + 1) & 1][r8] = row_of(lr);
+                            sr[(hb + 1) & 1][r8] = sal[lr];
+                            ax[(hb + 1) & 1][r8] = epi.aux(z, rowm(lr), c, rw[(hb + 1) & 1][r8]);
+                        }
+                    }
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        const int tm = hb >> 1, r = (hb & 1) * 8 + r8;
+                        const int m = m0 + lrow + tm * 32 + (r & 3) + 8 * (r >> 2);
+                        if constexpr (!CHECK && epi_has_full<Epi>::value) h3_assume_row(rw[hb & 1][r8]);
+                        if (!CHECK || m < g.M)
+                            epi.store2(z, m, c, acc[tm][0][r] * (sr[hb & 1][r8] * sc0), acc[tm][1][r] * (sr[hb & 1][r8] * sc1), rw[hb & 1][r8], cc,
+                                       ax[hb & 1][r8]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int lr = lrow + tm * 32 + (r & 3) + 8 * (r >> 2);
+                        const RowT rw = row_of(lr);
+                        const float sr = sal[lr];
+                        if constexpr (!CHECK && epi_has_full<Epi>::value) h3_assume_row(rw);
+                        if (!CHECK || m0 + lr < g.M) epi.store2(z, m0 + lr, c, acc[tm][0][r] * (sr * sc0), acc[tm][1][r] * (sr * sc1), rw, cc);
+                    }
                 }
             }
         } else {
+            int nn[2];
+            decltype(epi.col(0, 0)) cc[2];
+            float sc[2];
 #pragma unroll
-            for (int tm = 0; tm < 4; ++tm) {
-                decltype(epi.row(0, 0)) rw[16];
-                float sr[16];
+            for (int tn = 0; tn < 2; ++tn) {
+                nn[tn] = n0 + tn * 128 + wn * 32 + l31;
+                const int nc = min(nn[tn], g.N - 1);
+                cc[tn] = epi.col(z, nc);
+                sc[tn] = sb[(long)nc * sbm];
+            }
+            if constexpr (epi_has_aux<Epi>::value) {
+                // 16 half row blocks (tn, tm, half): operands of block i+1 are requested before the stores of block i
+                RowT rw[2][8];
+                float sr[2][8];
+                decltype(epi.aux(0, 0, 0, rw[0][0])) ax[2][8];
+                auto fetch = [&](int i, int set) {
+                    const int tn = i >> 3, tm = (i >> 1) & 3, half = i & 1;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = min(m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, g.M - 1);
-                    rw[r] = epi.row(z, m);
-                    sr[r] = sa[(long)m * sam];
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        const int r = half * 8 + r8;
+                        const int lr = lrow + tm * 32 + (r & 3) + 8 * (r >> 2);
+                        rw[set][r8] = row_of(lr);
+                        sr[set][r8] = sal[lr];
+                        ax[set][r8] = epi.aux(z, rowm(lr), min(nn[tn], g.N - 1), rw[set][r8]);
+                    }
+                };
+                fetch(0, 0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (i < 15) fetch(i + 1, (i + 1) & 1);
+                    const int tn = i >> 3, tm = (i >> 1) & 3, half = i & 1;
+                    if (nn[tn] < g.N) {
+#pragma unroll
+                        for (int r8 = 0; r8 < 8; ++r8) {
+                            const int r = half * 8 + r8;
+                            const int lr = lrow + tm * 32 + (r & 3) + 8 * (r >> 2);
+                            if constexpr (!CHECK && epi_has_full<Epi>::value) h3_assume_row(rw[i & 1][r8]);
+                            if (!CHECK || m0 + lr < g.M)
+                                epi.store(z, m0 + lr, nn[tn], acc[tm][tn][r] * (sr[i & 1][r8] * sc[tn]), rw[i & 1][r8], cc[tn], ax[i & 1][r8]);
+                        }
+                    }
                 }
+            } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (m < g.M) epi.store2(z, m, c, acc[tm][0][r] * (sr[r] * sc0), acc[tm][1][r] * (sr[r] * sc1), rw[r], cc);
+                for (int tn = 0; tn < 2; ++tn) {
+                    if (nn[tn] >= g.N) continue;
+#pragma unroll
+                    for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int lr = lrow + tm * 32 + (r & 3) + 8 * (r >> 2);
+                            const RowT rw = row_of(lr);
+                            const float sr = sal[lr];
+                            if constexpr (!CHECK && epi_has_full<Epi>::value) h3_assume_row(rw);
+                            if (!CHECK || m0 + lr < g.M) epi.store(z, m0 + lr, nn[tn], acc[tm][tn][r] * (sr * sc[tn]), rw, cc[tn]);
+                        }
+                    }
                 }
             }
         }
-    } else {
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int n = n0 + tn * 128 + wn * 32 + l31;
-            if (n >= g.N) continue;
-            const auto cc = epi.col(z, n);
-            const float sc = sb[(long)n * sbm];
-#pragma unroll
-            for (int tm = 0; tm < 4; ++tm) {
-                decltype(epi.row(0, 0)) rw[16];
-                float sr[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = min(m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, g.M - 1);
-                    rw[r] = epi.row(z, m);
-                    sr[r] = sa[(long)m * sam];
-                }
-                if constexpr (epi_has_aux<Epi>::value) {
-                    decltype(epi.aux(0, 0, 0, rw[0])) ax[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) ax[r] = epi.aux(z, min(m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, g.M - 1), n, rw[r]);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (m < g.M) epi.store(z, m, n, acc[tm][tn][r] * (sr[r] * sc), rw[r], cc, ax[r]);
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (m < g.M) epi.store(z, m, n, acc[tm][tn][r] * (sr[r] * sc), rw[r], cc);
-                    }
-                }
-            }
-        }
-    }
+    };
+    bool whole = m0 + 256 <= g.M;
+    if constexpr (epi_has_full<Epi>::value) whole = whole && epi.full(z, m0);
+    if (whole) epilogue(std::false_type{}); else epilogue(std::true_type{});
 }
 
 template <bool A_TR, bool B_TR, bool PAIRED, bool TWOSEG, class Epi, int VARIANT = 0, bool A_CONV = false>
@@ -568,7 +629,7 @@ inline hipError_t launch_gemm_h3x(H3Args g, int batches, Epi epi, hipStream_t st
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_kernel<A_TR, B_TR, PAIRED, TWOSEG, Epi, VARIANT, A_CONV>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            H3_LDS + (TWOSEG ? 1024 : 0));
+                            H3_LDS + 4096);
         attr_set = true;
     }
     g.tiles_m = (g.M + H3_BM - 1) / H3_BM;
@@ -592,7 +653,7 @@ inline hipError_t launch_gemm_h3x(H3Args g, int batches, Epi epi, hipStream_t st
     }
     if (TWOSEG && (g.seg[0].K < 64 || g.seg[1].K < 64 || g.seg[0].kchunk || g.seg[1].kchunk)) return hipErrorInvalidValue;
     if (A_CONV && (g.cv_cin < 64 || g.cv_cin % 16 || g.seg[0].K != g.cv_ntaps * g.cv_cin || !g.zero_row || batches != 1)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((gemm_h3_kernel<A_TR, B_TR, PAIRED, TWOSEG, Epi, VARIANT, A_CONV>), grid, dim3(H3_THREADS), H3_LDS + (TWOSEG ? 1024 : 0), st, g, epi);
+    hipLaunchKernelGGL((gemm_h3_kernel<A_TR, B_TR, PAIRED, TWOSEG, Epi, VARIANT, A_CONV>), grid, dim3(H3_THREADS), H3_LDS + 4096, st, g, epi);
     return hipGetLastError();
 }
 

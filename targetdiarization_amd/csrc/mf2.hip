@@ -35,7 +35,7 @@ struct EpiHidden {   // silu(acc*rs[m]*g[n] + b[n])                      mossfor
     const float* rs; const float* g; const float* b; float* out; long ld;
     __device__ Col2 col(int, int n) const { return Col2{g[n], b[n]}; }
     __device__ float row(int, int m) const { return rs[m]; }
-    __device__ void store(int, int m, int n, float v, float r, Col2 c) const { out[(long)m * ld + n] = siluf_acc(v * r * c.a + c.b); }
+    __device__ void store(int, int m, int n, float v, float r, Col2 c) const { out[(long)m * (int)ld + n] = siluf_acc(v * r * c.a + c.b); }
 };
 struct EpiQuadSim {  // relu(acc/256)^2 with key mask                       mossformer_block.py:256-262
     float* A; int G; int S; float inv_g;
@@ -50,7 +50,7 @@ struct EpiStore {    // plain store, per-batch stride
     float* out; long ld; long strideZ;
     __device__ EpiNone col(int, int) const { return EpiNone{}; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
-    __device__ void store(int z, int m, int n, float v, EpiNone, EpiNone) const { out[(long)z * strideZ + (long)m * ld + n] = v; }
+    __device__ void store(int z, int m, int n, float v, EpiNone, EpiNone) const { out[(long)z * strideZ + (long)m * (int)ld + n] = v; }
 };
 struct EpiAttnGate { // o = (att_u*v)*sigmoid(att_v*u)                       mossformer_block.py:217
     const float* vu; float* o; float* att_v; float* att_u; int G; int S; int E;
@@ -59,6 +59,7 @@ struct EpiAttnGate { // o = (att_u*v)*sigmoid(att_v*u)                       mos
         const int b = z / G, s = (z % G) * 256 + m;
         return s < S ? (long)b * S + s : -1L;
     }
+    __device__ bool full(int z, int m0) const { return (z % G) * 256 + m0 + 256 <= S; }
     __device__ float2 aux(int, int, int c, long rw) const {       // the gate's v, u operands
         if (rw < 0 || att_v) return make_float2(0.f, 0.f);
         return make_float2(vu[rw * (2 * E) + c], vu[rw * (2 * E) + E + c]);
@@ -81,7 +82,9 @@ struct EpiAttnGatePl { // the same gate with v, u read back from the K-major spl
     // there); the lane swap (DPP quad_perm [1,0,3,2]) and the unpacking happen in store2().
     const unsigned char* vuP; const float* inv; float* o; int G; int S; int Sp; int E;
     __device__ EpiNone col(int, int) const { return EpiNone{}; }
-    __device__ long row(int z, int m) const { const int b = z / G, s = (z % G) * 256 + m; return s < S ? (long)b * S + s : -1L; }
+    // row(): element offset of the token's output row (staged in LDS by the kernel, once per tile row), -1 for group padding
+    __device__ long row(int z, int m) const { const int b = z / G, s = (z % G) * 256 + m; return s < S ? ((long)b * S + s) * E : -1L; }
+    __device__ bool full(int z, int m0) const { return (z % G) * 256 + m0 + 256 <= S; }
     __device__ int2 aux(int z, int m, int c, long) const {
         const int b = z / G, s = min((z % G) * 256 + m, S - 1);
         const int c2 = c & ~1;
@@ -98,7 +101,7 @@ struct EpiAttnGatePl { // the same gate with v, u read back from the K-major spl
         a.u = (unsigned short)(hv >> sh); bq.u = (unsigned short)(lv >> sh); cq.u = (unsigned short)(hu >> sh); d.u = (unsigned short)(lu >> sh);
         const float k = inv[0];
         const float v = ((float)a.h + (float)bq.h) * k, u = ((float)cq.h + (float)d.h) * k;
-        o[rw * E + c] = (au * v) * sigmoidf_acc(av * u);
+        o[rw + c] = (au * v) * sigmoidf_acc(av * u);
     }
 };
 struct EpiBiasPrelu { // prelu_scalar(acc + b[n])                            mossformer_block.py:405-408
@@ -107,21 +110,21 @@ struct EpiBiasPrelu { // prelu_scalar(acc + b[n])                            mos
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
     __device__ void store(int, int m, int n, float v, EpiNone, Col2 c) const {
         v += c.a;
-        out[(long)m * ld + n] = v >= 0.f ? v : c.b * v;
+        out[(long)m * (int)ld + n] = v >= 0.f ? v : c.b * v;
     }
 };
 struct EpiBiasSilu { const float* b; float* out; long ld;
     __device__ float col(int, int n) const { return b[n]; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
-    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { out[(long)m * ld + n] = siluf_acc(v + c); } };
+    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { out[(long)m * (int)ld + n] = siluf_acc(v + c); } };
 struct EpiBiasRelu { const float* b; float* out; long ld;
     __device__ float col(int, int n) const { return b[n]; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
-    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { out[(long)m * ld + n] = fmaxf(v + c, 0.f); } };
+    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { out[(long)m * (int)ld + n] = fmaxf(v + c, 0.f); } };
 struct EpiBias { const float* b; float* out; long ld;   // b may be null
     __device__ float col(int, int n) const { return b ? b[n] : 0.f; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
-    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { out[(long)m * ld + n] = v + c; } };
+    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { out[(long)m * (int)ld + n] = v + c; } };
 struct EpiBiasHalves { const float* b; float* out; long M;   // [M][2C] written as [2][M][C] (the two mask branches)
     __device__ float col(int, int n) const { return b[n]; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
@@ -129,8 +132,8 @@ struct EpiBiasHalves { const float* b; float* out; long M;   // [M][2C] written 
 struct EpiBiasResidual { const float* b; float* x; long ld;   // x += acc + b   mossformer_block.py:424-425
     __device__ float col(int, int n) const { return b[n]; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
-    __device__ float aux(int, int m, int n, EpiNone) const { return x[(long)m * ld + n]; }
-    __device__ void store(int, int m, int n, float v, EpiNone, float c, float xo) const { x[(long)m * ld + n] = xo + (v + c); } };
+    __device__ float aux(int, int m, int n, EpiNone) const { return x[(long)m * (int)ld + n]; }
+    __device__ void store(int, int m, int n, float v, EpiNone, float c, float xo) const { x[(long)m * (int)ld + n] = xo + (v + c); } };
 struct EpiPosEnc {   // z = acc + pe[s][n]*scale ; x = z                     mossformer2.py:490-496
     const float* pe; const float* scale; float* zout; float* x; int S;
     __device__ float col(int, int) const { return scale[0]; }
@@ -1125,6 +1128,7 @@ int tdx_h3_gemm_variant(const void* pa, const float* sa, const void* pb, const f
     else if (variant == 2) r = tdx::launch_gemm_h3<false, EpiBias, 2>(g, 1, e, (hipStream_t)stream);
     else if (variant == 3) r = tdx::launch_gemm_h3<false, EpiBias, 3>(g, 1, e, (hipStream_t)stream);
     else if (variant == 4) r = tdx::launch_gemm_h3<false, EpiBias, 4>(g, 1, e, (hipStream_t)stream);
+    else if (variant == 8) r = tdx::launch_gemm_h3<false, EpiBias, 8>(g, 1, e, (hipStream_t)stream);
     else r = tdx::launch_gemm_h3<false, EpiBias, 0>(g, 1, e, (hipStream_t)stream);
     return r == hipSuccess ? TDX_OK : tdx::fail_hip(r, __FILE__, __LINE__);
 }
@@ -1179,7 +1183,50 @@ __global__ __launch_bounds__(512, 2) void fill_bench_kernel(const unsigned char*
     acc += reinterpret_cast<const float*>(lds)[threadIdx.x];
     if (acc == 123.456f) sink[0] = acc;
 }
+// GEMM-shaped fill: every block streams k-tiles of an A slab and a B slab (256 rows each, `stride` bytes per row) shared with
+// the other blocks of its XCD, either as the row-major planes deliver them (MODE 1: a wave instruction covers 16 rows x 64 B)
+// or as contiguous 16 KB tiles of the same slabs (MODE 0: 1 KB per wave instruction).
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void fill_bench2_kernel(const unsigned char* __restrict__ src, int stride, int iters, float* sink) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const long slab = 256L * stride;
+    const unsigned char* a = src + (long)(xcd * 4 + ((local >> 3) & 3)) * slab;
+    const unsigned char* b = src + 32 * slab + (long)((local >> 2) & 1) * slab;
+    const unsigned char* base = wave < 4 ? a : b;
+    const int kts = stride / 64;
+    float acc = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        const int kt = it % kts;
+        unsigned char* dst = lds + (it & 3) * 32768;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int slot = (wave & 3) * 4 + j;
+            const unsigned char* g = MODE == 0 ? base + (long)kt * 16384 + slot * 1024 + lane * 16
+                                               : base + (long)(slot * 16 + (lane >> 2)) * stride + kt * 64 + (lane & 3) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(dst + (wave * 4 + j) * 1024), 16, 0, 0);
+        }
+        if ((it & 1) == 1) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    acc += reinterpret_cast<const float*>(lds)[threadIdx.x];
+    if (acc == 123.456f) sink[0] = acc;
+}
 }  // namespace
+extern "C" int tdx_fill_bench2(int mode, const void* src, int stride, int blocks, int iters, float* sink, void* stream) {
+    static bool set = false;
+    if (!set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&fill_bench2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&fill_bench2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        set = true;
+    }
+    if (mode == 0) hipLaunchKernelGGL(fill_bench2_kernel<0>, dim3(blocks), dim3(512), 131072, (hipStream_t)stream, (const unsigned char*)src, stride, iters, sink);
+    else hipLaunchKernelGGL(fill_bench2_kernel<1>, dim3(blocks), dim3(512), 131072, (hipStream_t)stream, (const unsigned char*)src, stride, iters, sink);
+    return hipGetLastError() == hipSuccess ? TDX_OK : TDX_E_HIP;
+}
 extern "C" int tdx_fill_bench(int mode, const void* src, long bytes_per_block, int blocks, int iters, float* sink, void* stream) {
     static bool set = false;
     if (!set) {

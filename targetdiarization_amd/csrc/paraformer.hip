@@ -128,16 +128,16 @@ __global__ __launch_bounds__(256) void pf_softmax_kernel(float* __restrict__ sc,
 struct EpiBiasP { const float* b; float* out; long ld;
     __device__ float col(int, int n) const { return b[n]; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
-    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { out[(long)m * ld + n] = v + c; } };
+    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { out[(long)m * (int)ld + n] = v + c; } };
 struct EpiBiasReluP { const float* b; float* out; long ld;
     __device__ float col(int, int n) const { return b[n]; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
-    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { out[(long)m * ld + n] = fmaxf(v + c, 0.f); } };
+    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { out[(long)m * (int)ld + n] = fmaxf(v + c, 0.f); } };
 struct EpiBiasResP { const float* b; float* x; long ld;
     __device__ float col(int, int n) const { return b[n]; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
-    __device__ float aux(int, int m, int n, EpiNone) const { return x[(long)m * ld + n]; }
-    __device__ void store(int, int m, int n, float v, EpiNone, float c, float xo) const { x[(long)m * ld + n] = xo + (v + c); } };
+    __device__ float aux(int, int m, int n, EpiNone) const { return x[(long)m * (int)ld + n]; }
+    __device__ void store(int, int m, int n, float v, EpiNone, float c, float xo) const { x[(long)m * (int)ld + n] = xo + (v + c); } };
 struct EpiScores { float* sc; int Sp; float scale;     // q k^T * dk^-0.5 -> [z][Sp][Sp]
     __device__ EpiNone col(int, int) const { return EpiNone{}; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }

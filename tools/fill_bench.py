@@ -24,3 +24,22 @@ for (label, per_block) in [("L2-resident 64 KB/block", 65536), ("1 MB/block (L2+
         gb = 256 * iters * 32768 / 1e9
         print(f"{label}: mode {'LDS-DMA' if mode == 0 else 'regs+ds_write'}: {gb / t / 1e3:.2f} TB/s chip = {gb / t / 256:.1f} GB/s per CU ({t / iters * 1e6:.2f} us per 32 KB)", flush=True)
     del src
+
+# GEMM-shaped slabs: row-major planes pattern (16 rows x 64 B per wave instruction) against contiguous tiles of the same bytes
+g = l.tdx_fill_bench2; g.restype = C.c_int
+g.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+for stride in (2048, 8192):
+    src = torch.empty(34 * 256 * stride, dtype=torch.uint8, device=dev).random_(0, 255)
+    for mode in (0, 1, 0, 1):
+        iters = 8192
+        for _ in range(2):
+            g(mode, src.data_ptr(), stride, 256, iters, sink.data_ptr(), None)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g(mode, src.data_ptr(), stride, 256, iters, sink.data_ptr(), None)
+        e1.record(); torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3
+        gb = 256 * iters * 32768 / 1e9
+        print(f"GEMM slabs, row stride {stride}: {'contiguous 16 KB tiles' if mode == 0 else '16 rows x 64 B per instr'}: "
+              f"{gb / t / 256:.1f} GB/s per CU ({t / iters * 1e6:.2f} us per 32 KB)", flush=True)
+    del src

@@ -206,7 +206,9 @@ __global__ __launch_bounds__(256) void chain_conv24_kernel(DirectConvArgs a) {
         }
     }
     // ---- epilogue (EpiChain): D col = l31 (output channel), row = (r&3) + 8*(r>>2) + 4*h (pixel of the row)
-    const float bias = l31 < DC_C ? a.b[l31] : 0.f;
+    // (touch(): loaded values are waited for in straight-line code before the conditional stores, see gemm.hpp)
+    float bias = l31 < DC_C ? a.b[l31] : 0.f;
+    tdx::touch(bias);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int y = y0 + 2 * wave + r;
@@ -217,6 +219,8 @@ __global__ __launch_bounds__(256) void chain_conv24_kernel(DirectConvArgs a) {
             const int x = min(x0 + (i & 3) + 8 * (i >> 2) + 4 * h, a.W - 1);
             nx[i] = (a.spin && l31 < DC_C) ? a.o1[(((long)b * a.H + y) * a.W + x) * a.ldo1 + a.next_off + l31] : 0.f;
         }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tdx::touch(nx[i]);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int x = x0 + (i & 3) + 8 * (i >> 2) + 4 * h;

@@ -25,6 +25,7 @@
 // of the fragment pairs k-values {8kc+j, 8kc+4+j} — the same permutation on A and B, hence
 // a valid (re-ordered) K summation.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -88,6 +89,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 //              void store(int z,int m,int n,float v,Row,Col) const;            // plain
 //              void store2(int z,int m,int c,float v0,float v1,Row,Col) const; // PAIRED }
 struct EpiNone {};
+// "this value is needed here": an empty asm that reads the registers of a loaded value, so that the compiler places its
+// (counted) s_waitcnt in straight-line code ahead of the stores.  Left pending across the per-row / per-column branches of
+// a store loop, a load makes the waitcnt pass re-wait vmcnt(0) at every block entry — and vmcnt counts stores.
+template <class T> __device__ __forceinline__ void touch(T& v) {
+    if constexpr (!std::is_empty<T>::value && sizeof(T) % 4 == 0) {
+        float* w = reinterpret_cast<float*>(&v);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(T) / 4); ++i) asm volatile("" : "+v"(w[i]));
+    }
+}
 // optional member  Aux aux(int z,int m,int n,Row) const : a value the epilogue has to LOAD per
 // output element (residual, gate operands ...).  The kernels fetch it for 16 elements at a time
 // before the first store of the batch, so the loads overlap instead of forming a load->store
@@ -356,8 +367,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, E
     // ---- epilogue: D col = l31, row = (r&3) + 8*(r>>2) + 4*h ----
     // per-column constants (bias, gain ...) are fetched once per lane; per-row constants and the
     // per-element auxiliary loads are fetched for 16 rows before the first store of the batch
-    const auto c0 = epi.col(z, n0 + nl0);
-    const auto c1 = epi.col(z, PAIRED ? n0 + nl0 : n0 + nl1);
+    // (a tile whose rows all exist takes a branch-free path: per-row `if (m < M)` blocks make the compiler re-wait vmcnt(0)
+    // at every block entry, and vmcnt counts stores — one store round trip per store)
+    auto epilogue = [&](auto tag) {
+    constexpr bool CHECK = decltype(tag)::value;
+    auto c0 = epi.col(z, n0 + nl0);
+    auto c1 = epi.col(z, PAIRED ? n0 + nl0 : n0 + nl1);
+    touch(c0); touch(c1);
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
         decltype(epi.row(0, 0)) rw[16];
@@ -375,11 +391,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, E
                 if constexpr (!PAIRED) ax1[r] = epi.aux(z, m, n0 + nl1, rw[r]);
             }
 #pragma unroll
+            for (int r = 0; r < 16; ++r) { touch(rw[r]); touch(ax0[r]); if constexpr (!PAIRED) touch(ax1[r]); }
+#pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const float v0 = tm == 0 ? acc00[r] : acc10[r];
                 const float v1 = tm == 0 ? acc01[r] : acc11[r];
-                if (m < g.M) {
+                if (!CHECK || m < g.M) {
                     if constexpr (PAIRED) {
                         epi.store2(z, m, n0 + nl0, v0, v1, rw[r], c0, ax0[r]);
                     } else {
@@ -390,11 +408,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, E
             }
         } else {
 #pragma unroll
+            for (int r = 0; r < 16; ++r) touch(rw[r]);
+#pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const float v0 = tm == 0 ? acc00[r] : acc10[r];
                 const float v1 = tm == 0 ? acc01[r] : acc11[r];
-                if (m < g.M) {
+                if (!CHECK || m < g.M) {
                     if constexpr (PAIRED) {
                         epi.store2(z, m, n0 + nl0, v0, v1, rw[r], c0);
                     } else {
@@ -405,6 +425,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmArgs g, E
             }
         }
     }
+    };
+    if (m0 + GEMM_BM <= g.M) epilogue(std::false_type{}); else epilogue(std::true_type{});
 }
 
 template <bool A_KMAJOR, bool B_KMAJOR, bool PAIRED, bool SHIFT, class Epi, int VARIANT = 0, bool CONV = false>

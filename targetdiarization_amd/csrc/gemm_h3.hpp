@@ -502,15 +502,22 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
     }
     const float* sb = sl.sb + (long)zl1 * sl.strideSB + (long)zl2 * sl.strideSB2;
     const int sbm = sl.sb_mul;
-    const int lrow = wm * 128 + 4 * h;                      // this lane's first row inside the tile
+    // this lane's first row and column inside the tile — laundered, so that the epilogue's index arithmetic is not hoisted
+    // above the main loop (where it would be spilled: the loop runs at the register limit)
+    // (and again inside each of the two paths: common subexpressions of the paths would be hoisted to their dominator, all
+    // 128 row indices at once, and spilled there)
+    const int lrow0 = wm * 128 + 4 * h, lcol0 = wn * 32 + l31;
     auto row_of = [&](int lr) -> RowT { if constexpr (HAS_ROW) return rwl[lr]; else return RowT{}; };
     auto epilogue = [&](auto tag) {
         constexpr bool CHECK = decltype(tag)::value;
+        int lrow = lrow0, lcol = lcol0;
+        asm volatile("" : "+v"(lrow), "+v"(lcol));
         auto rowm = [&](int lr) { return CHECK ? min(m0 + lr, g.M - 1) : m0 + lr; };
         if constexpr (PAIRED) {
-            const int c = n0 + wn * 32 + l31;
-            const auto cc = epi.col(z, c);
-            const float sc0 = sb[(long)c * sbm], sc1 = sb[(long)(g.pair_off + c) * sbm];
+            const int c = n0 + lcol;
+            auto cc = epi.col(z, c);
+            float sc0 = sb[(long)c * sbm], sc1 = sb[(long)(g.pair_off + c) * sbm];
+            touch(cc); touch(sc0); touch(sc1);
             if constexpr (epi_has_aux<Epi>::value) {
                 RowT rw[2][8];
                 float sr[2][8];
@@ -524,16 +531,21 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
                 }
 #pragma unroll
                 for (int hb = 0; hb < 8; ++hb) {
+                    __builtin_amdgcn_sched_barrier(0);      // (keeps the LDS reads of later blocks from being hoisted: registers)
                     if (hb < 7) {
+                        int lb = lrow + ((hb + 1) >> 1) * 32;       // (laundered per block: index arithmetic stays inside its block)
+                        asm volatile("" : "+v"(lb));
 #pragma unroll
                         for (int r8 = 0; r8 < 8; ++r8) {
                             const int r = ((hb + 1) & 1) * 8 + r8;
-                            const int lr = lrow + ((hb + 1) >> 1) * 32 + (r & 3) + 8 * (r >> 2);
+                            const int lr = lb + (r & 3) + 8 * (r >> 2);
                             rw[(hb + 1) & 1][r8] = row_of(lr);
                             sr[(hb + 1) & 1][r8] = sal[lr];
                             ax[(hb + 1) & 1][r8] = epi.aux(z, rowm(lr), c, rw[(hb + 1) & 1][r8]);
                         }
                     }
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8) touch(ax[hb & 1][r8]);
 #pragma unroll
                     for (int r8 = 0; r8 < 8; ++r8) {
                         const int tm = hb >> 1, r = (hb & 1) * 8 + r8;
@@ -563,40 +575,54 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
             float sc[2];
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn) {
-                nn[tn] = n0 + tn * 128 + wn * 32 + l31;
+                nn[tn] = n0 + tn * 128 + lcol;
                 const int nc = min(nn[tn], g.N - 1);
                 cc[tn] = epi.col(z, nc);
                 sc[tn] = sb[(long)nc * sbm];
             }
+            touch(cc[0]); touch(cc[1]); touch(sc[0]); touch(sc[1]);
             if constexpr (epi_has_aux<Epi>::value) {
-                // 16 half row blocks (tn, tm, half): operands of block i+1 are requested before the stores of block i
-                RowT rw[2][8];
-                float sr[2][8];
-                decltype(epi.aux(0, 0, 0, rw[0][0])) ax[2][8];
+                // 16 half row blocks (tn, tm, half): the aux operands of block i+1 are requested before the stores of block i
+                // (row values and row scales are LDS reads — lgkmcnt, not vmcnt — and are fetched where they are used)
+                decltype(epi.aux(0, 0, 0, RowT{})) ax[2][8];
                 auto fetch = [&](int i, int set) {
                     const int tn = i >> 3, tm = (i >> 1) & 3, half = i & 1;
+                    int lb = lrow + tm * 32;            // (laundered per block: index arithmetic stays inside its block)
+                    asm volatile("" : "+v"(lb));
 #pragma unroll
                     for (int r8 = 0; r8 < 8; ++r8) {
                         const int r = half * 8 + r8;
-                        const int lr = lrow + tm * 32 + (r & 3) + 8 * (r >> 2);
-                        rw[set][r8] = row_of(lr);
-                        sr[set][r8] = sal[lr];
-                        ax[set][r8] = epi.aux(z, rowm(lr), min(nn[tn], g.N - 1), rw[set][r8]);
+                        const int lr = lb + (r & 3) + 8 * (r >> 2);
+                        ax[set][r8] = epi.aux(z, rowm(lr), min(nn[tn], g.N - 1), row_of(lr));
                     }
                 };
                 fetch(0, 0);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
+                    __builtin_amdgcn_sched_barrier(0);      // (keeps the work of later blocks from being hoisted: registers)
                     if (i < 15) fetch(i + 1, (i + 1) & 1);
                     const int tn = i >> 3, tm = (i >> 1) & 3, half = i & 1;
+                    RowT rw[8];
+                    float sr[8];
+                    int lb = lrow + tm * 32;
+                    asm volatile("" : "+v"(lb));
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        const int r = half * 8 + r8;
+                        const int lr = lb + (r & 3) + 8 * (r >> 2);
+                        rw[r8] = row_of(lr);
+                        sr[r8] = sal[lr];
+                    }
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8) touch(ax[i & 1][r8]);
                     if (nn[tn] < g.N) {
 #pragma unroll
                         for (int r8 = 0; r8 < 8; ++r8) {
                             const int r = half * 8 + r8;
-                            const int lr = lrow + tm * 32 + (r & 3) + 8 * (r >> 2);
-                            if constexpr (!CHECK && epi_has_full<Epi>::value) h3_assume_row(rw[i & 1][r8]);
+                            const int lr = lb + (r & 3) + 8 * (r >> 2);
+                            if constexpr (!CHECK && epi_has_full<Epi>::value) h3_assume_row(rw[r8]);
                             if (!CHECK || m0 + lr < g.M)
-                                epi.store(z, m0 + lr, nn[tn], acc[tm][tn][r] * (sr[i & 1][r8] * sc[tn]), rw[i & 1][r8], cc[tn], ax[i & 1][r8]);
+                                epi.store(z, m0 + lr, nn[tn], acc[tm][tn][r] * (sr[r8] * sc[tn]), rw[r8], cc[tn], ax[i & 1][r8]);
                         }
                     }
                 }

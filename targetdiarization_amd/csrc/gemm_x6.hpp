@@ -262,9 +262,13 @@ __global__ __launch_bounds__(X6_THREADS, 2) void gemm_x6_kernel(GemmArgs g, Epi 
 
     // ---- epilogue: D col = l31, row = (r&3) + 8*(r>>2) + 4*h.  Per-row constants and the
     // auxiliary loads of 16 rows are fetched before the first store of the batch.
+    // (whole tiles take a branch-free path: per-row `if (m < M)` blocks cost one store round trip per store, see gemm_h3.hpp)
+    auto epilogue = [&](auto tag) {
+    constexpr bool CHECK = decltype(tag)::value;
     if constexpr (PAIRED) {
         const int c = n0 + wn * 32 + l31;
-        const auto cc = epi.col(z, c);
+        auto cc = epi.col(z, c);
+        touch(cc);
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm) {
             decltype(epi.row(0, 0)) rw[16];
@@ -275,15 +279,19 @@ __global__ __launch_bounds__(X6_THREADS, 2) void gemm_x6_kernel(GemmArgs g, Epi 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) ax[r] = epi.aux(z, min(m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, g.M - 1), c, rw[r]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (m < g.M) epi.store2(z, m, c, acc[tm][0][r], acc[tm][1][r], rw[r], cc, ax[r]);
-                }
-            } else {
+                for (int r = 0; r < 16; ++r) { touch(rw[r]); touch(ax[r]); }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (m < g.M) epi.store2(z, m, c, acc[tm][0][r], acc[tm][1][r], rw[r], cc);
+                    if (!CHECK || m < g.M) epi.store2(z, m, c, acc[tm][0][r], acc[tm][1][r], rw[r], cc, ax[r]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) touch(rw[r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (!CHECK || m < g.M) epi.store2(z, m, c, acc[tm][0][r], acc[tm][1][r], rw[r], cc);
                 }
             }
         }
@@ -292,7 +300,8 @@ __global__ __launch_bounds__(X6_THREADS, 2) void gemm_x6_kernel(GemmArgs g, Epi 
         for (int tn = 0; tn < 2; ++tn) {
             const int n = n0 + tn * 128 + wn * 32 + l31;
             if (n >= g.N) continue;
-            const auto cc = epi.col(z, n);
+            auto cc = epi.col(z, n);
+            touch(cc);
 #pragma unroll
             for (int tm = 0; tm < 4; ++tm) {
                 decltype(epi.row(0, 0)) rw[16];
@@ -303,20 +312,26 @@ __global__ __launch_bounds__(X6_THREADS, 2) void gemm_x6_kernel(GemmArgs g, Epi 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ax[r] = epi.aux(z, min(m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, g.M - 1), n, rw[r]);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (m < g.M) epi.store(z, m, n, acc[tm][tn][r], rw[r], cc, ax[r]);
-                    }
-                } else {
+                    for (int r = 0; r < 16; ++r) { touch(rw[r]); touch(ax[r]); }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int m = m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (m < g.M) epi.store(z, m, n, acc[tm][tn][r], rw[r], cc);
+                        if (!CHECK || m < g.M) epi.store(z, m, n, acc[tm][tn][r], rw[r], cc, ax[r]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) touch(rw[r]);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (!CHECK || m < g.M) epi.store(z, m, n, acc[tm][tn][r], rw[r], cc);
                     }
                 }
             }
         }
     }
+    };
+    if (m0 + X6_BM <= g.M) epilogue(std::false_type{}); else epilogue(std::true_type{});
 }
 
 // !PAIRED: N any value <= rows readable in 256-row tiles of W (pad the weight buffer), columns

@@ -51,6 +51,7 @@
 // In both cases the swizzle is applied on the per-lane SOURCE address of the DMA (its LDS
 // destination is lane-linear) and on the fragment read.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -65,6 +66,7 @@ constexpr int H3_ROWB = 64;                   // bytes per LDS row (16 k x 2 pla
 constexpr int H3_OPER = 256 * H3_ROWB;        // 16 KB per operand tile
 constexpr int H3_STAGE = 2 * H3_OPER;         // A then B
 constexpr int H3_NBUF = 4;
+constexpr int H3_AUX_AHEAD = 3;               // PAIRED epilogues: half row blocks of aux() operands requested ahead of the stores
 constexpr int H3_LDS = H3_NBUF * H3_STAGE;    // 128 KB
 
 struct H3Seg {
@@ -96,6 +98,7 @@ struct H3Args {
     // taps or (0,0) for 1, or `zero_row` (>= 4*cv_cin zero bytes) outside the image; B = [N][ntaps*cv_cin] planes.
     int cv_Hin, cv_Win, cv_Hout, cv_Wout, cv_stride, cv_ntaps, cv_cin;
     const unsigned char* zero_row;
+    int dbg;                     // diagnostics (env TDX_H3_DEBUG, timing only, wrong results): 1 = no epilogue
 };
 
 inline H3Seg h3_seg(const void* A, const float* sa, long lda, const void* B, const float* sb, long ldb, int K) {
@@ -494,7 +497,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
     // `if (m < M)` blocks make the compiler's waitcnt pass re-wait vmcnt(0) at every block entry, i.e. one store round
     // trip per store: 17 us per tile; (ii) row scales and the functor's row() values come from LDS (staged before the
     // prologue); (iii) column constants are fetched before the first store and aux() operands half a row block ahead.
-    if constexpr (VARIANT == 8) {       // (timing: no epilogue)
+    if (g.dbg & 1) {                    // (timing: no epilogue)
         float x = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) x += acc[0][0][r] + acc[1][1][r] + acc[2][0][r] + acc[3][1][r];
@@ -519,41 +522,46 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
             float sc0 = sb[(long)c * sbm], sc1 = sb[(long)(g.pair_off + c) * sbm];
             touch(cc); touch(sc0); touch(sc1);
             if constexpr (epi_has_aux<Epi>::value) {
-                RowT rw[2][8];
-                float sr[2][8];
-                decltype(epi.aux(0, 0, 0, rw[0][0])) ax[2][8];
+                // 8 half row blocks; the aux operands (cold HBM reads) run H3_AUX_AHEAD blocks ahead of the stores: with one
+                // block ahead a CU has 32 KB of requests in flight against 2-4 us of loaded HBM latency (= 2.7 TB/s chip-wide)
+                constexpr int AH = H3_AUX_AHEAD;
+                decltype(epi.aux(0, 0, 0, RowT{})) ax[AH + 1][8];
+                auto fetch = [&](int hb) {
+                    int lb = lrow + (hb >> 1) * 32;       // (laundered per block: index arithmetic stays inside its block)
+                    asm volatile("" : "+v"(lb));
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const int lr = lrow + (r & 3) + 8 * (r >> 2);
-                    rw[0][r] = row_of(lr);
-                    sr[0][r] = sal[lr];
-                    ax[0][r] = epi.aux(z, rowm(lr), c, rw[0][r]);
-                }
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        const int r = (hb & 1) * 8 + r8;
+                        const int lr = lb + (r & 3) + 8 * (r >> 2);
+                        ax[hb % (AH + 1)][r8] = epi.aux(z, rowm(lr), c, row_of(lr));
+                    }
+                };
+#pragma unroll
+                for (int hb = 0; hb < AH; ++hb) fetch(hb);
 #pragma unroll
                 for (int hb = 0; hb < 8; ++hb) {
-                    __builtin_amdgcn_sched_barrier(0);      // (keeps the LDS reads of later blocks from being hoisted: registers)
-                    if (hb < 7) {
-                        int lb = lrow + ((hb + 1) >> 1) * 32;       // (laundered per block: index arithmetic stays inside its block)
-                        asm volatile("" : "+v"(lb));
+                    __builtin_amdgcn_sched_barrier(0);      // (keeps the work of later blocks from being hoisted: registers)
+                    if (hb + AH < 8) fetch(hb + AH);
+                    RowT rw[8];
+                    float sr[8];
+                    int lb = lrow + (hb >> 1) * 32;
+                    asm volatile("" : "+v"(lb));
 #pragma unroll
-                        for (int r8 = 0; r8 < 8; ++r8) {
-                            const int r = ((hb + 1) & 1) * 8 + r8;
-                            const int lr = lb + (r & 3) + 8 * (r >> 2);
-                            rw[(hb + 1) & 1][r8] = row_of(lr);
-                            sr[(hb + 1) & 1][r8] = sal[lr];
-                            ax[(hb + 1) & 1][r8] = epi.aux(z, rowm(lr), c, rw[(hb + 1) & 1][r8]);
-                        }
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        const int r = (hb & 1) * 8 + r8;
+                        const int lr = lb + (r & 3) + 8 * (r >> 2);
+                        rw[r8] = row_of(lr);
+                        sr[r8] = sal[lr];
                     }
 #pragma unroll
-                    for (int r8 = 0; r8 < 8; ++r8) touch(ax[hb & 1][r8]);
+                    for (int r8 = 0; r8 < 8; ++r8) touch(ax[hb % (AH + 1)][r8]);
 #pragma unroll
                     for (int r8 = 0; r8 < 8; ++r8) {
                         const int tm = hb >> 1, r = (hb & 1) * 8 + r8;
-                        const int m = m0 + lrow + tm * 32 + (r & 3) + 8 * (r >> 2);
-                        if constexpr (!CHECK && epi_has_full<Epi>::value) h3_assume_row(rw[hb & 1][r8]);
-                        if (!CHECK || m < g.M)
-                            epi.store2(z, m, c, acc[tm][0][r] * (sr[hb & 1][r8] * sc0), acc[tm][1][r] * (sr[hb & 1][r8] * sc1), rw[hb & 1][r8], cc,
-                                       ax[hb & 1][r8]);
+                        const int lr = lb + (r & 3) + 8 * (r >> 2);
+                        if constexpr (!CHECK && epi_has_full<Epi>::value) h3_assume_row(rw[r8]);
+                        if (!CHECK || m0 + lr < g.M)
+                            epi.store2(z, m0 + lr, c, acc[tm][0][r] * (sr[r8] * sc0), acc[tm][1][r] * (sr[r8] * sc1), rw[r8], cc, ax[hb % (AH + 1)][r8]);
                     }
                 }
             } else {
@@ -679,6 +687,8 @@ inline hipError_t launch_gemm_h3x(H3Args g, int batches, Epi epi, hipStream_t st
     }
     if (TWOSEG && (g.seg[0].K < 64 || g.seg[1].K < 64 || g.seg[0].kchunk || g.seg[1].kchunk)) return hipErrorInvalidValue;
     if (A_CONV && (g.cv_cin < 64 || g.cv_cin % 16 || g.seg[0].K != g.cv_ntaps * g.cv_cin || !g.zero_row || batches != 1)) return hipErrorInvalidValue;
+    static const int dbg = [] { const char* e = getenv("TDX_H3_DEBUG"); return e ? atoi(e) : 0; }();
+    g.dbg = dbg;
     hipLaunchKernelGGL((gemm_h3_kernel<A_TR, B_TR, PAIRED, TWOSEG, Epi, VARIANT, A_CONV>), grid, dim3(H3_THREADS), H3_LDS + 4096, st, g, epi);
     return hipGetLastError();
 }

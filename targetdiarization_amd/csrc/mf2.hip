@@ -80,28 +80,31 @@ struct EpiAttnGatePl { // the same gate with v, u read back from the K-major spl
     // fp32 copy of v|u, which then need not be written (8 KB per token less in conv17<4>).  aux() returns the RAW words (the
     // kernel issues it one half block ahead of the stores: anything that consumed the loads there would wait for them
     // there); the lane swap (DPP quad_perm [1,0,3,2]) and the unpacking happen in store2().
-    const unsigned char* vuP; const float* inv; float* o; int G; int S; int Sp; int E;
-    __device__ EpiNone col(int, int) const { return EpiNone{}; }
+    const unsigned char* vuP; const float* inv; float* o; int G; int S; int Sp; int E; int Ea;    // Ea = E (0: diagnostics, all rows read row 0)
+    __device__ float col(int, int) const { return inv[0]; }      // (fetched once, ahead of the stores: a load inside store2() could not be hoisted over them)
     // row(): element offset of the token's output row (staged in LDS by the kernel, once per tile row), -1 for group padding
     __device__ long row(int z, int m) const { const int b = z / G, s = (z % G) * 256 + m; return s < S ? ((long)b * S + s) * E : -1L; }
     __device__ bool full(int z, int m0) const { return (z % G) * 256 + m0 + 256 <= S; }
     __device__ int2 aux(int z, int m, int c, long) const {
         const int b = z / G, s = min((z % G) * 256 + m, S - 1);
         const int c2 = c & ~1;
-        const unsigned char* p = vuP + ((long)b * Sp + s) * (8L * E) + (c2 >> 5) * 128 + (c2 & 31) * 2 + (c & 1) * 64;
+        const unsigned char* p = vuP + (long)b * Sp * (8L * Ea) + (long)s * (8 * Ea) + (c2 >> 5) * 128 + (c2 & 31) * 2 + (c & 1) * 64;
         return make_int2(*reinterpret_cast<const int*>(p), *reinterpret_cast<const int*>(p + 4L * E));
     }
-    __device__ void store2(int, int, int c, float av, float au, long rw, EpiNone, int2 w) const {
-        const int odd = c & 1;
-        const int ov = __builtin_amdgcn_mov_dpp(w.x, 0xB1, 0xF, 0xF, true), ou = __builtin_amdgcn_mov_dpp(w.y, 0xB1, 0xF, 0xF, true);
+    __device__ void store2(int, int, int c, float av, float au, long rw, float k, int2 w) const {
+        // even lane: own = (hi[c], hi[c+1]), partner = (lo[c], lo[c+1]); odd lane: own = (lo[c-1], lo[c]), partner = (hi[c-1], hi[c]).
+        // One byte permute per operand builds (hi[c], lo[c]) as a packed f16 pair; the rest is packed fp32 math.
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const unsigned ov = (unsigned)__builtin_amdgcn_mov_dpp(w.x, 0xB1, 0xF, 0xF, true), ou = (unsigned)__builtin_amdgcn_mov_dpp(w.y, 0xB1, 0xF, 0xF, true);
         if (rw < 0) return;
-        const unsigned hv = odd ? ov : w.x, lv = odd ? w.x : ov, hu = odd ? ou : w.y, lu = odd ? w.y : ou;
-        const int sh = odd * 16;
-        union { unsigned short u; _Float16 h; } a, bq, cq, d;
-        a.u = (unsigned short)(hv >> sh); bq.u = (unsigned short)(lv >> sh); cq.u = (unsigned short)(hu >> sh); d.u = (unsigned short)(lu >> sh);
-        const float k = inv[0];
-        const float v = ((float)a.h + (float)bq.h) * k, u = ((float)cq.h + (float)d.h) * k;
-        o[rw + c] = (au * v) * sigmoidf_acc(av * u);
+        const unsigned sel = (c & 1) ? 0x03020706u : 0x05040100u;        // v_perm_b32: bytes 0-3 = own word, 4-7 = partner word
+        const h2 pv = __builtin_bit_cast(h2, __builtin_amdgcn_perm(ov, (unsigned)w.x, sel));
+        const h2 pu = __builtin_bit_cast(h2, __builtin_amdgcn_perm(ou, (unsigned)w.y, sel));
+        f2 s = f2{(float)pv[0], (float)pu[0]} + f2{(float)pv[1], (float)pu[1]};       // (v, u) / k
+        s *= f2{k, k};
+        const f2 t = f2{au, av} * s;                                                  // (att_u*v, att_v*u)
+        o[rw + c] = t[0] * sigmoidf_acc(t[1]);
     }
 };
 struct EpiBiasPrelu { // prelu_scalar(acc + b[n])                            mossformer_block.py:405-408
@@ -426,7 +429,7 @@ int attention_core_h3(const unsigned char* qkP, const float* qks, const unsigned
         g.seg[1].strideSB = 1; g.seg[1].strideSB2 = 0;
         g.nseg = 2; g.M = 256; g.N = E; g.pair_off = E;
         if (o && !vu) {       // the model: gate operands from the planes (no fp32 copy of v|u exists)
-            if (tdx::launch_gemm_h3x<false, true, true, true>(g, B * G, EpiAttnGatePl{vuP, st, o, G, S, Sp, E}, st_) != hipSuccess)
+            if (tdx::launch_gemm_h3x<false, true, true, true>(g, B * G, EpiAttnGatePl{vuP, st, o, G, S, Sp, E, (getenv("TDX_H3_DEBUG") && (atoi(getenv("TDX_H3_DEBUG")) & 4)) ? 0 : E}, st_) != hipSuccess)
                 return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
             return TDX_OK;
         }
@@ -1128,7 +1131,6 @@ int tdx_h3_gemm_variant(const void* pa, const float* sa, const void* pb, const f
     else if (variant == 2) r = tdx::launch_gemm_h3<false, EpiBias, 2>(g, 1, e, (hipStream_t)stream);
     else if (variant == 3) r = tdx::launch_gemm_h3<false, EpiBias, 3>(g, 1, e, (hipStream_t)stream);
     else if (variant == 4) r = tdx::launch_gemm_h3<false, EpiBias, 4>(g, 1, e, (hipStream_t)stream);
-    else if (variant == 8) r = tdx::launch_gemm_h3<false, EpiBias, 8>(g, 1, e, (hipStream_t)stream);
     else r = tdx::launch_gemm_h3<false, EpiBias, 0>(g, 1, e, (hipStream_t)stream);
     return r == hipSuccess ? TDX_OK : tdx::fail_hip(r, __FILE__, __LINE__);
 }

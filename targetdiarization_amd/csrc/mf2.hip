@@ -80,7 +80,7 @@ struct EpiAttnGatePl { // the same gate with v, u read back from the K-major spl
     // fp32 copy of v|u, which then need not be written (8 KB per token less in conv17<4>).  aux() returns the RAW words (the
     // kernel issues it one half block ahead of the stores: anything that consumed the loads there would wait for them
     // there); the lane swap (DPP quad_perm [1,0,3,2]) and the unpacking happen in store2().
-    const unsigned char* vuP; const float* inv; float* o; int G; int S; int Sp; int E; int Ea;    // Ea = E (0: diagnostics, all rows read row 0)
+    const unsigned char* vuP; const float* inv; float* o; int G; int S; int Sp; int E;
     __device__ float col(int, int) const { return inv[0]; }      // (fetched once, ahead of the stores: a load inside store2() could not be hoisted over them)
     // row(): element offset of the token's output row (staged in LDS by the kernel, once per tile row), -1 for group padding
     __device__ long row(int z, int m) const { const int b = z / G, s = (z % G) * 256 + m; return s < S ? ((long)b * S + s) * E : -1L; }
@@ -88,7 +88,7 @@ struct EpiAttnGatePl { // the same gate with v, u read back from the K-major spl
     __device__ int2 aux(int z, int m, int c, long) const {
         const int b = z / G, s = min((z % G) * 256 + m, S - 1);
         const int c2 = c & ~1;
-        const unsigned char* p = vuP + (long)b * Sp * (8L * Ea) + (long)s * (8 * Ea) + (c2 >> 5) * 128 + (c2 & 31) * 2 + (c & 1) * 64;
+        const unsigned char* p = vuP + (long)b * Sp * (8L * E) + (long)s * (8 * E) + (c2 >> 5) * 128 + (c2 & 31) * 2 + (c & 1) * 64;
         return make_int2(*reinterpret_cast<const int*>(p), *reinterpret_cast<const int*>(p + 4L * E));
     }
     __device__ void store2(int, int, int c, float av, float au, long rw, float k, int2 w) const {
@@ -429,7 +429,7 @@ int attention_core_h3(const unsigned char* qkP, const float* qks, const unsigned
         g.seg[1].strideSB = 1; g.seg[1].strideSB2 = 0;
         g.nseg = 2; g.M = 256; g.N = E; g.pair_off = E;
         if (o && !vu) {       // the model: gate operands from the planes (no fp32 copy of v|u exists)
-            if (tdx::launch_gemm_h3x<false, true, true, true>(g, B * G, EpiAttnGatePl{vuP, st, o, G, S, Sp, E, (getenv("TDX_H3_DEBUG") && (atoi(getenv("TDX_H3_DEBUG")) & 4)) ? 0 : E}, st_) != hipSuccess)
+            if (tdx::launch_gemm_h3x<false, true, true, true>(g, B * G, EpiAttnGatePl{vuP, st, o, G, S, Sp, E}, st_) != hipSuccess)
                 return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
             return TDX_OK;
         }

@@ -227,7 +227,7 @@ __device__ __forceinline__ void h3_stage_dma_only(const unsigned char* const (&g
 
 // A_TR / B_TR: operand in K-major planes.  TWOSEG: two K segments (same operand formats, their own
 // pointers and scales).  VARIANT != 0: timing-only diagnostics (wrong results): 1 no LDS-DMA in
-// the loop, 2 no fragment reads, 3 neither, 4 no barrier.
+// the loop, 2 no fragment reads, 3 neither, 4 no barrier, 9 no vmcnt wait in the steady loop.
 // optional functor member full(z, m0): all 256 rows of the tile are real rows (row() >= 0 for the functors whose row() marks
 // padding with -1) — lets the epilogue take its branch-free path
 template <class E, class = void> struct epi_has_full { static constexpr bool value = false; };
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
         // stages before the MFMAs do, the accumulators are rescaled between stage nkt0-1 and stage nkt0.
 #define H3_STEADY(FULLN, PH, LIMIT, TILE0)                                                                             \
             for (; t + 4 < (LIMIT); ++t) {                                                                             \
-                H3_WAIT_VM(8);                                                                                         \
+                if (VARIANT != 9) H3_WAIT_VM(8);                                                                       \
                 if (VARIANT != 4) H3_BARRIER();                                                                        \
                 if (wave_on)                                                                                           \
                     h3_stage<A_TR, B_TR, FULLN, VARIANT != 2 && VARIANT != 3, VARIANT != 1 && VARIANT != 3, PH>(       \

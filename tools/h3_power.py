@@ -15,7 +15,7 @@ for (m, n, k) in [(65536, 2048, 2048), (255968, 2176, 512)]:
         pa, sa = split(a); pb, sb = split(w)
         if label == "zeros":
             pa.zero_(); pb.zero_()
-        for v in (0, 1, 4, 9, 2, 3):
+        for v in (0, 9, 1, 2, 3):
             for _ in range(2):
                 gv(pa.data_ptr(), sa.data_ptr(), pb.data_ptr(), sb.data_ptr(), bias.data_ptr(), c.data_ptr(), m, n, k, v, None)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1219,6 +1219,41 @@ __global__ __launch_bounds__(512, 2) void fill_bench2_kernel(const unsigned char
     if (acc == 123.456f) sink[0] = acc;
 }
 }  // namespace
+// column-strip streaming (the K^T[V|U] operand pattern): block = (row range, strip); per k row it fetches `seg` contiguous bytes
+// of a `pitch`-byte row; 32 KB per iteration.  pitch == seg: a contiguous stream.
+namespace {
+__global__ __launch_bounds__(512, 2) void fill_bench3_kernel(const unsigned char* __restrict__ src, long pitch, int seg, long rows_per_block, int strips, int iters, float* sink) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int strip = blockIdx.x % strips;
+    const long row0 = (long)(blockIdx.x / strips) * rows_per_block;
+    const int per_row = seg / 1024;                  // 1 KB instructions per row
+    const int rows_per_it = 32 / per_row;
+    float acc = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        unsigned char* dst = lds + (it & 3) * 32768;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = wave * 4 + j;              // instruction 0..31 of this iteration
+            const long r = row0 + ((long)it * rows_per_it + i / per_row) % rows_per_block;
+            const unsigned char* g = src + r * pitch + (long)strip * seg + (i % per_row) * 1024 + lane * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+        }
+        if ((it & 1) == 1) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    acc += reinterpret_cast<const float*>(lds)[threadIdx.x];
+    if (acc == 123.456f) sink[0] = acc;
+}
+}  // namespace
+extern "C" int tdx_fill_bench3(const void* src, long pitch, int seg, long rows_per_block, int strips, int blocks, int iters, float* sink, void* stream) {
+    static bool set = false;
+    if (!set) { hipFuncSetAttribute(reinterpret_cast<const void*>(&fill_bench3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); set = true; }
+    hipLaunchKernelGGL(fill_bench3_kernel, dim3(blocks), dim3(512), 131072, (hipStream_t)stream, (const unsigned char*)src, pitch, seg, rows_per_block, strips, iters, sink);
+    return hipGetLastError() == hipSuccess ? TDX_OK : TDX_E_HIP;
+}
 extern "C" int tdx_fill_bench2(int mode, const void* src, int stride, int blocks, int iters, float* sink, void* stream) {
     static bool set = false;
     if (!set) {

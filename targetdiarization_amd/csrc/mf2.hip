@@ -393,19 +393,22 @@ int attention_core_h3(const unsigned char* qkP, const float* qks, const unsigned
         if (tdx::launch_h3_split_rows(Abuf, 256, AbufP, Asc, (long)B * Sp, 256, st_) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
     }
     {   // Kvu[b][d][ch] = (1/S) sum_t lin_k[t][d] vu[t][ch], split over token chunks         mossformer_block.py:286,289
-        // M = 128 (d): the 128 rows of waves 4-7 do not exist and those waves only feed the ring; lin_k is the
-        // K-major A operand (its transposing reads are the slow ones: better on 4 waves than, with the operands
-        // swapped, on all 8 for a half-empty N tile), v|u the K-major B operand with full 256-column tiles
+        // M = 128 (d): the 128 rows of waves 4-7 do not exist and those waves only feed the ring; lin_k is the A operand — once
+        // more as ROW-major planes (kmajor_to_rows_kernel; in the fp32 similarity buffer, which is dead after its split): the
+        // transposing LDS reads of a K-major A operand bound this launch — v|u the K-major B operand with full 256-column tiles
+        unsigned char* lin_kR = reinterpret_cast<unsigned char*>(Abuf);
+        hipLaunchKernelGGL(kmajor_to_rows_kernel, dim3(Sp / 64, B), dim3(256), 0, st_, lin_k, lin_kR, Sp);
+        LAUNCH_CHECK();
         tdx::H3Args g{};
-        g.seg[0] = tdx::h3_seg(lin_k, st + 1, 512, vuP, st, 4L * 2 * E, kchunk);
+        g.seg[0] = tdx::h3_seg(lin_kR, st + 1, 4L * Sp, vuP, st, 4L * 2 * E, kchunk);
         g.seg[0].sa_mul = 0; g.seg[0].sb_mul = 0;
         g.seg[0].zdiv = splits;
-        g.seg[0].strideA = (long)Sp * 512; g.seg[0].strideA2 = (long)kchunk * 512;
+        g.seg[0].strideA = (long)Sp * 512; g.seg[0].strideA2 = (long)kchunk * 4;
         g.seg[0].strideB = (long)Sp * 4 * 2 * E; g.seg[0].strideB2 = (long)kchunk * 4 * 2 * E;
         g.seg[0].kchunk = kchunk; g.seg[0].ktotal = Sp;
         g.nseg = 1; g.M = QK; g.N = 2 * E;
         EpiStore e{slab, 2L * E, (long)QK * 2 * E};
-        if (tdx::launch_gemm_h3x<true, true, false, false>(g, B * splits, e, st_) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+        if (tdx::launch_gemm_h3x<false, true, false, false>(g, B * splits, e, st_) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
         const long per = (long)QK * 2 * E;
         const int nb = (int)((per / 4 + 255) / 256);
         float* bmax = kvus + B;          // [B][nb] block maxima

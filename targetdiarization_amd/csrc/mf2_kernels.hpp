@@ -416,6 +416,34 @@ __global__ __launch_bounds__(256) void fsmn_tail_kernel(const float* __restrict_
     if (lane == 0) hs[m] = inv;
 }
 
+// lin_k, written token-major by conv17<3> as K-major planes [b][Sp][4 groups][hi 64 B | lo 64 B], again as ROW-major planes
+// [b][128 d][Sp/8][hi 16 B | lo 16 B] (row pitch 4*Sp bytes): as the 128-row A operand of K^T[V|U] it then needs no
+// transposing LDS reads — 16 of the 24 `ds_read_b64_tr_b16` gathers per wave and stage, which bound that launch (880 -> 523 us).
+// Block = 64 tokens of one batch: 32 KB through LDS; 8 lanes write one full 128-B line (4 token octets x 2 planes of one d).
+__global__ __launch_bounds__(256) void kmajor_to_rows_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int Sp) {
+    __shared__ __attribute__((aligned(16))) unsigned char tile[64 * 512];
+    const int b = blockIdx.y, t0 = blockIdx.x * 64, tid = threadIdx.x;
+    const unsigned char* s = src + ((long)b * Sp + t0) * 512;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        *reinterpret_cast<uint4*>(tile + (i * 256 + tid) * 16) = *reinterpret_cast<const uint4*>(s + (long)(i * 256 + tid) * 16);
+    __syncthreads();
+    unsigned char* d0 = dst + (long)b * Sp * 512 + (long)(t0 >> 3) * 32;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = i * 256 + tid;                    // 16-B output chunk: (d, octet, plane), (octet, plane) fastest
+        const int pl = c & 1, o = (c >> 1) & 7, d = c >> 4;
+        const unsigned char* p = tile + (8 * o) * 512 + (d >> 5) * 128 + pl * 64 + (d & 31) * 2;
+        unsigned short v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const unsigned short*>(p + k * 512);
+        uint4 w;
+        w.x = v[0] | ((unsigned)v[1] << 16); w.y = v[2] | ((unsigned)v[3] << 16);
+        w.z = v[4] | ((unsigned)v[5] << 16); w.w = v[6] | ((unsigned)v[7] << 16);
+        *reinterpret_cast<uint4*>(d0 + (long)d * (4L * Sp) + o * 32 + pl * 16) = w;
+    }
+}
+
 // x3 path: kvu[b][d][ch] = (sum_sp slab[b][sp][d][ch]) / S in fp32, and per block the max |value| (bmax[b][block];
 // no atomics: 1024 waves hammering one word cost 250 us).  Then kvu_planes_kernel reduces the block maxima and
 // re-writes kvu as K-major planes KvuP[b][d][64][2][32] with one exact power-of-two scale per sample (the B

@@ -10,7 +10,7 @@ gv.argtypes = [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p]
 for (m, n, k) in [(256, 256, 512), (65536, 2048, 2048), (255968, 2176, 512)]:
     a = torch.randn(m, k, device=dev); w = torch.randn(n, k, device=dev); bias = torch.zeros(n, device=dev); c = torch.empty(m, n, device=dev)
     pa, sa = split(a); pb, sb = split(w)
-    for v in (0, 8, 0, 8):
+    for v in (0, 1, 2, 3, 4, 9, 0):
         for _ in range(2):
             gv(pa.data_ptr(), sa.data_ptr(), pb.data_ptr(), sb.data_ptr(), bias.data_ptr(), c.data_ptr(), m, n, k, v, None)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -232,6 +232,10 @@ __device__ __forceinline__ void h3_stage_dma_only(const unsigned char* const (&g
 // padding with -1) — lets the epilogue take its branch-free path
 template <class E, class = void> struct epi_has_full { static constexpr bool value = false; };
 template <class E> struct epi_has_full<E, decltype((void)&E::full, void())> { static constexpr bool value = true; };
+// optional functor members ptr(z, m, n) -> float* (address of output element (m, n) of a single row-major output), ldm()
+// (its row pitch in elements) and put(p, v, row, col) (= store() to that address): see the epilogue
+template <class E, class = void> struct epi_has_ptr { static constexpr bool value = false; };
+template <class E> struct epi_has_ptr<E, decltype((void)&E::ptr, void())> { static constexpr bool value = true; };
 template <class T> __device__ __forceinline__ void h3_assume_row(const T&) {}
 __device__ __forceinline__ void h3_assume_row(long rw) { __builtin_assume(rw >= 0); }
 
@@ -638,6 +642,23 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn) {
                     if (nn[tn] >= g.N) continue;
+                    if constexpr (epi_has_ptr<Epi>::value) {
+                        // functors with one row-major output: the element address is formed ONCE per lane and column block;
+                        // the rows of the wave tile are compile-time multiples of the (uniform) row pitch away — one 64-bit
+                        // add per store instead of a 64-bit multiply-add chain
+                        float* const p0 = epi.ptr(z, m0 + lrow, nn[tn]);
+                        const long ldm = epi.ldm();
+#pragma unroll
+                        for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int k = tm * 32 + (r & 3) + 8 * (r >> 2);
+                                const RowT rw = row_of(lrow + k);
+                                const float sr = sal[lrow + k];
+                                if (!CHECK || m0 + lrow + k < g.M) epi.put(p0 + k * ldm, acc[tm][tn][r] * (sr * sc[tn]), rw, cc[tn]);
+                            }
+                        }
+                    } else {
 #pragma unroll
                     for (int tm = 0; tm < 4; ++tm) {
 #pragma unroll
@@ -648,6 +669,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
                             if constexpr (!CHECK && epi_has_full<Epi>::value) h3_assume_row(rw);
                             if (!CHECK || m0 + lr < g.M) epi.store(z, m0 + lr, nn[tn], acc[tm][tn][r] * (sr * sc[tn]), rw, cc[tn]);
                         }
+                    }
                     }
                 }
             }

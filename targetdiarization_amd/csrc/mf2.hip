@@ -36,6 +36,9 @@ struct EpiHidden {   // silu(acc*rs[m]*g[n] + b[n])                      mossfor
     __device__ Col2 col(int, int n) const { return Col2{g[n], b[n]}; }
     __device__ float row(int, int m) const { return rs[m]; }
     __device__ void store(int, int m, int n, float v, float r, Col2 c) const { out[(long)m * (int)ld + n] = siluf_acc(v * r * c.a + c.b); }
+    __device__ float* ptr(int, int m, int n) const { return out + (long)m * (int)ld + n; }
+    __device__ long ldm() const { return ld; }
+    __device__ void put(float* p, float v, float r, Col2 c) const { *p = siluf_acc(v * r * c.a + c.b); }
 };
 struct EpiQuadSim {  // relu(acc/256)^2 with key mask                       mossformer_block.py:256-262
     float* A; int G; int S; float inv_g;
@@ -115,19 +118,31 @@ struct EpiBiasPrelu { // prelu_scalar(acc + b[n])                            mos
         v += c.a;
         out[(long)m * (int)ld + n] = v >= 0.f ? v : c.b * v;
     }
+    __device__ float* ptr(int, int m, int n) const { return out + (long)m * (int)ld + n; }
+    __device__ long ldm() const { return ld; }
+    __device__ void put(float* p, float v, EpiNone, Col2 c) const { v += c.a; *p = v >= 0.f ? v : c.b * v; }
 };
 struct EpiBiasSilu { const float* b; float* out; long ld;
     __device__ float col(int, int n) const { return b[n]; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
-    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { out[(long)m * (int)ld + n] = siluf_acc(v + c); } };
+    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { out[(long)m * (int)ld + n] = siluf_acc(v + c); }
+    __device__ float* ptr(int, int m, int n) const { return out + (long)m * (int)ld + n; }
+    __device__ long ldm() const { return ld; }
+    __device__ void put(float* p, float v, EpiNone, float c) const { *p = siluf_acc(v + c); } };
 struct EpiBiasRelu { const float* b; float* out; long ld;
     __device__ float col(int, int n) const { return b[n]; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
-    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { out[(long)m * (int)ld + n] = fmaxf(v + c, 0.f); } };
+    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { out[(long)m * (int)ld + n] = fmaxf(v + c, 0.f); }
+    __device__ float* ptr(int, int m, int n) const { return out + (long)m * (int)ld + n; }
+    __device__ long ldm() const { return ld; }
+    __device__ void put(float* p, float v, EpiNone, float c) const { *p = fmaxf(v + c, 0.f); } };
 struct EpiBias { const float* b; float* out; long ld;   // b may be null
     __device__ float col(int, int n) const { return b ? b[n] : 0.f; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
-    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { out[(long)m * (int)ld + n] = v + c; } };
+    __device__ void store(int, int m, int n, float v, EpiNone, float c) const { out[(long)m * (int)ld + n] = v + c; }
+    __device__ float* ptr(int, int m, int n) const { return out + (long)m * (int)ld + n; }
+    __device__ long ldm() const { return ld; }
+    __device__ void put(float* p, float v, EpiNone, float c) const { *p = v + c; } };
 struct EpiBiasHalves { const float* b; float* out; long M;   // [M][2C] written as [2][M][C] (the two mask branches)
     __device__ float col(int, int n) const { return b[n]; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }

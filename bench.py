@@ -303,7 +303,7 @@ def main():
                        "parallelism": f"{world} independent replicas (windows sharded, no collective)"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_H3_TFLOPS, "unit": "TFLOP/s",
                          "frac": (ach / PEAK_H3_TFLOPS) if ach else None, "traffic": traffic,
-                         "kernel": "gemm_h3_kernel<to_hidden+to_qk: split-f16 x3 MFMA over pre-split planes, ScaleNorm+SiLU epilogue>",
+                         "kernel": "gemm_h3_kernel<to_hidden+to_qk: split-f16 x3 MFMA over pre-split planes, ScaleNorm gain/bias epilogue (SiLU applied by the consuming depthwise convolution)>",
                          "peak_note": "algorithmic fp32-accurate FLOP/s ceiling of the kernel = dense f16 MFMA peak 2500 / 3 passes; "
                                       "vs the fp32-input MFMA peak (157.3) the same number is frac_vs_f32_mfma_peak",
                          "frac_vs_f32_mfma_peak": (ach / PEAK_F32_MFMA_TFLOPS) if ach else None,

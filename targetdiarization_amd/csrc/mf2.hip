@@ -31,15 +31,19 @@ constexpr int C = 512, HID = 2048, QK = 128, HQ = HID + QK, INNER = 256;
 // ------------------------------------------------------------------ GEMM epilogues
 // (concept in gemm.hpp: col()/row() fetch per-column / per-row constants once, store() writes)
 struct Col2 { float a, b; };
-struct EpiHidden {   // silu(acc*rs[m]*g[n] + b[n])                      mossformer_block.py:89-102
+template <bool ACT>
+struct EpiHiddenT {  // silu(acc*rs[m]*g[n] + b[n])                      mossformer_block.py:89-102
+    // ACT = false: the pre-activation is stored and the consuming depthwise convolution applies SiLU as it loads (Conv17Args::silu_in)
     const float* rs; const float* g; const float* b; float* out; long ld;
+    __device__ static float f(float x) { return ACT ? siluf_acc(x) : x; }
     __device__ Col2 col(int, int n) const { return Col2{g[n], b[n]}; }
     __device__ float row(int, int m) const { return rs[m]; }
-    __device__ void store(int, int m, int n, float v, float r, Col2 c) const { out[(long)m * (int)ld + n] = siluf_acc(v * r * c.a + c.b); }
+    __device__ void store(int, int m, int n, float v, float r, Col2 c) const { out[(long)m * (int)ld + n] = f(v * r * c.a + c.b); }
     __device__ float* ptr(int, int m, int n) const { return out + (long)m * (int)ld + n; }
     __device__ long ldm() const { return ld; }
-    __device__ void put(float* p, float v, float r, Col2 c) const { *p = siluf_acc(v * r * c.a + c.b); }
+    __device__ void put(float* p, float v, float r, Col2 c) const { *p = f(v * r * c.a + c.b); }
 };
+using EpiHidden = EpiHiddenT<true>;
 struct EpiQuadSim {  // relu(acc/256)^2 with key mask                       mossformer_block.py:256-262
     float* A; int G; int S; float inv_g;
     __device__ bool col(int z, int n) const { return (z % G) * 256 + n < S; }
@@ -856,28 +860,28 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
         {
             const bool prof = h->ev_used < h->ev0.size();
             if (prof) hipEventRecord(h->ev0[h->ev_used], st);
-            TRY(linear_h3(hp, hs, (int)M, w.hWhq, HQ, C, EpiHidden{rs, w.ghq, w.bhq, hid, HQ}, st));
+            TRY(linear_h3(hp, hs, (int)M, w.hWhq, HQ, C, EpiHiddenT<false>{rs, w.ghq, w.bhq, hid, HQ}, st));    // (SiLU in conv17)
             if (prof) { hipEventRecord(h->ev1[h->ev_used], st); h->ev_used++; }
         }
         {
             Conv17Args a{};
             a.in = hid; a.ld_in = HQ; a.col0 = 0; a.wT = w.cw_h; a.C = HID; a.out = nullptr; a.ld_out = HID; a.S = S; a.Sp = Sp;
-            a.hp = vuP; a.sv = w.sv_vu;
+            a.hp = vuP; a.sv = w.sv_vu; a.silu_in = 1;
             TRY(launch_conv17<4>(a, B, st));          // v|u as K-major planes only: GEMM operands and (read back in the epilogue) gate operands
             Conv17Args q{};
             q.in = hid; q.ld_in = HQ; q.col0 = HID; q.wT = w.cw_qk; q.C = QK; q.S = S; q.Sp = Sp; q.gamma = w.gamma; q.beta = w.beta;
             q.rot_cos = rc; q.rot_sin = rsn; q.head_stride = (long)B * Sp * QK;
-            q.hp = (unsigned char*)qk4; q.hs = qks; q.sv = w.sv_lk;
+            q.hp = (unsigned char*)qk4; q.hs = qks; q.sv = w.sv_lk; q.silu_in = 1;
             TRY(launch_conv17<3>(q, B, st));          // the four heads as planes
         }
         TRY(attention_core_h3((const unsigned char*)qk4, qks, vuP, nullptr, w.st, B, S, 1024, P.splits, P.kchunk, Abuf, AbufP, Asc, slab, kvu, KvuP,
                               kvus, o, nullptr, nullptr, st));
         hipLaunchKernelGGL((rowscale_split_kernel<1024, false>), rows4(M), dim3(256), 0, st, o, rs, hp, hs, M, S);
         LAUNCH_CHECK();
-        TRY(linear_h3(hp, hs, (int)M, w.hWo, C, 1024, EpiHidden{rs, w.go, w.bo, t, C}, st));
+        TRY(linear_h3(hp, hs, (int)M, w.hWo, C, 1024, EpiHiddenT<false>{rs, w.go, w.bo, t, C}, st));
         {
             Conv17Args a{};
-            a.in = t; a.ld_in = C; a.col0 = 0; a.wT = w.cw_o; a.C = C; a.out = x; a.ld_out = C; a.S = S; a.Sp = Sp;
+            a.in = t; a.ld_in = C; a.col0 = 0; a.wT = w.cw_o; a.C = C; a.out = x; a.ld_out = C; a.S = S; a.Sp = Sp; a.silu_in = 1;
             TRY(launch_conv17<1>(a, B, st));
         }
         if (h->taps && l == 0) hipMemcpyAsync(ws + P.tap0, x, M * C * sizeof(float), hipMemcpyDeviceToDevice, st);

@@ -236,6 +236,13 @@ template <class E> struct epi_has_full<E, decltype((void)&E::full, void())> { st
 // (its row pitch in elements) and put(p, v, row, col) (= store() to that address): see the epilogue
 template <class E, class = void> struct epi_has_ptr { static constexpr bool value = false; };
 template <class E> struct epi_has_ptr<E, decltype((void)&E::ptr, void())> { static constexpr bool value = true; };
+// optional scale folding: rowmul(row) is multiplied into the LDS-staged row scale, colmul(col) into the column scale (then
+// put_scaled(p, v, row, col) receives v with both factors in); PAIRED: pairmul(col) -> float2 into the two column scales
+// (then store2_scaled(...)).  Saves the per-element multiplies of functors whose output is scale-linear in v.
+template <class E, class = void> struct epi_has_rowmul { static constexpr bool value = false; };
+template <class E> struct epi_has_rowmul<E, decltype((void)&E::rowmul, void())> { static constexpr bool value = true; };
+template <class E, class = void> struct epi_has_pairmul { static constexpr bool value = false; };
+template <class E> struct epi_has_pairmul<E, decltype((void)&E::pairmul, void())> { static constexpr bool value = true; };
 template <class T> __device__ __forceinline__ void h3_assume_row(const T&) {}
 __device__ __forceinline__ void h3_assume_row(long rw) { __builtin_assume(rw >= 0); }
 
@@ -376,6 +383,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
     if (tid < 256) {
         sa_own = (sl.sa + (long)zl1 * sl.strideSA + (long)zl2 * sl.strideSA2)[(long)min(m0 + tid, g.M - 1) * sl.sa_mul];
         if constexpr (HAS_ROW) rw_own = epi.row(z, min(m0 + tid, g.M - 1));
+        if constexpr (epi_has_rowmul<Epi>::value) sa_own *= epi.rowmul(rw_own);
     }
 
     const H3Seg& sg0 = g.seg[0];
@@ -525,6 +533,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
             auto cc = epi.col(z, c);
             float sc0 = sb[(long)c * sbm], sc1 = sb[(long)(g.pair_off + c) * sbm];
             touch(cc); touch(sc0); touch(sc1);
+            if constexpr (epi_has_pairmul<Epi>::value) { const float2 pm = epi.pairmul(cc); sc0 *= pm.x; sc1 *= pm.y; }
             if constexpr (epi_has_aux<Epi>::value) {
                 // 8 half row blocks; the aux operands (cold HBM reads) run H3_AUX_AHEAD blocks ahead of the stores: with one
                 // block ahead a CU has 32 KB of requests in flight against 2-4 us of loaded HBM latency (= 2.7 TB/s chip-wide)
@@ -564,8 +573,12 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
                         const int tm = hb >> 1, r = (hb & 1) * 8 + r8;
                         const int lr = lb + (r & 3) + 8 * (r >> 2);
                         if constexpr (!CHECK && epi_has_full<Epi>::value) h3_assume_row(rw[r8]);
-                        if (!CHECK || m0 + lr < g.M)
-                            epi.store2(z, m0 + lr, c, acc[tm][0][r] * (sr[r8] * sc0), acc[tm][1][r] * (sr[r8] * sc1), rw[r8], cc, ax[hb % (AH + 1)][r8]);
+                        if (!CHECK || m0 + lr < g.M) {
+                            if constexpr (epi_has_pairmul<Epi>::value)
+                                epi.store2_scaled(z, m0 + lr, c, acc[tm][0][r] * (sr[r8] * sc0), acc[tm][1][r] * (sr[r8] * sc1), rw[r8], cc, ax[hb % (AH + 1)][r8]);
+                            else
+                                epi.store2(z, m0 + lr, c, acc[tm][0][r] * (sr[r8] * sc0), acc[tm][1][r] * (sr[r8] * sc1), rw[r8], cc, ax[hb % (AH + 1)][r8]);
+                        }
                     }
                 }
             } else {
@@ -648,6 +661,8 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
                         // add per store instead of a 64-bit multiply-add chain
                         float* const p0 = epi.ptr(z, m0 + lrow, nn[tn]);
                         const long ldm = epi.ldm();
+                        float sct = sc[tn];
+                        if constexpr (epi_has_rowmul<Epi>::value) sct *= epi.colmul(cc[tn]);
 #pragma unroll
                         for (int tm = 0; tm < 4; ++tm) {
 #pragma unroll
@@ -655,7 +670,10 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
                                 const int k = tm * 32 + (r & 3) + 8 * (r >> 2);
                                 const RowT rw = row_of(lrow + k);
                                 const float sr = sal[lrow + k];
-                                if (!CHECK || m0 + lrow + k < g.M) epi.put(p0 + k * ldm, acc[tm][tn][r] * (sr * sc[tn]), rw, cc[tn]);
+                                if (!CHECK || m0 + lrow + k < g.M) {
+                                    if constexpr (epi_has_rowmul<Epi>::value) epi.put_scaled(p0 + k * ldm, acc[tm][tn][r] * (sr * sct), rw, cc[tn]);
+                                    else epi.put(p0 + k * ldm, acc[tm][tn][r] * (sr * sct), rw, cc[tn]);
+                                }
                             }
                         }
                     } else {

@@ -42,6 +42,9 @@ struct EpiHiddenT {  // silu(acc*rs[m]*g[n] + b[n])                      mossfor
     __device__ float* ptr(int, int m, int n) const { return out + (long)m * (int)ld + n; }
     __device__ long ldm() const { return ld; }
     __device__ void put(float* p, float v, float r, Col2 c) const { *p = f(v * r * c.a + c.b); }
+    __device__ float rowmul(float r) const { return r; }              // (folded into the kernel's row / column scales:
+    __device__ float colmul(Col2 c) const { return c.a; }             //  put_scaled() gets v * r * c.a)
+    __device__ void put_scaled(float* p, float v, float, Col2 c) const { *p = f(v + c.b); }
 };
 using EpiHidden = EpiHiddenT<true>;
 struct EpiQuadSim {  // relu(acc/256)^2 with key mask                       mossformer_block.py:256-262
@@ -97,6 +100,21 @@ struct EpiAttnGatePl { // the same gate with v, u read back from the K-major spl
         const int c2 = c & ~1;
         const unsigned char* p = vuP + (long)b * Sp * (8L * E) + (long)s * (8 * E) + (c2 >> 5) * 128 + (c2 & 31) * 2 + (c & 1) * 64;
         return make_int2(*reinterpret_cast<const int*>(p), *reinterpret_cast<const int*>(p + 4L * E));
+    }
+    // the plane scale k and the sigmoid's -log2(e) folded into the kernel's column scales: store2_scaled() gets
+    // av' = -log2(e) * k * att_v and au' = k * att_u
+    __device__ float2 pairmul(float k) const { return make_float2(-1.4426950408889634f * k, k); }
+    __device__ void store2_scaled(int, int, int c, float av, float au, long rw, float, int2 w) const {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const unsigned ov = (unsigned)__builtin_amdgcn_mov_dpp(w.x, 0xB1, 0xF, 0xF, true), ou = (unsigned)__builtin_amdgcn_mov_dpp(w.y, 0xB1, 0xF, 0xF, true);
+        if (rw < 0) return;
+        const unsigned sel = (c & 1) ? 0x03020706u : 0x05040100u;
+        const h2 pv = __builtin_bit_cast(h2, __builtin_amdgcn_perm(ov, (unsigned)w.x, sel));
+        const h2 pu = __builtin_bit_cast(h2, __builtin_amdgcn_perm(ou, (unsigned)w.y, sel));
+        const f2 s = f2{(float)pv[0], (float)pu[0]} + f2{(float)pv[1], (float)pu[1]};        // (v, u) / k
+        const f2 t = f2{au, av} * s;                                                         // (att_u*v, -log2(e)*att_v*u)
+        o[rw + c] = t[0] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t[1]));
     }
     __device__ void store2(int, int, int c, float av, float au, long rw, float k, int2 w) const {
         // even lane: own = (hi[c], hi[c+1]), partner = (lo[c], lo[c+1]); odd lane: own = (lo[c-1], lo[c]), partner = (hi[c-1], hi[c]).

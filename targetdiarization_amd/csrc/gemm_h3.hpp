@@ -249,6 +249,7 @@ __device__ __forceinline__ void h3_assume_row(long rw) { __builtin_assume(rw >= 
 template <bool A_TR, bool B_TR, bool PAIRED, bool TWOSEG, class Epi, int VARIANT = 0, bool A_CONV = false>
 __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi epi) {
     static_assert(!A_CONV || (!A_TR && !TWOSEG), "A_CONV: row-major A planes, one weight segment");
+    constexpr bool PINGPONG = VARIANT == 5;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -493,9 +494,73 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
             }                                                                                                          \
             if (wave_on) h3_stage<A_TR, B_TR, FULLN, false, false, PH>(acc, ah, al, bh, bl, lds, f, gp, 0, lds);       \
         }
+        if constexpr (PINGPONG) {
+            // ---- ping-pong main loop (plain mode: one segment, no convolution).  The two waves of a SIMD (w and w+4) never
+            // mix MFMAs with loads: while group 0 (waves 0-3) issues the 24 MFMAs of tile t back to back, group 1 reads its
+            // fragments of tile t and issues its LDS-DMA pieces; then they swap — two barriers per k-tile:
+            //     G0:  MFMA(t)           | frags(t+1), DMA(t+4)
+            //     G1:  frags(t), DMA(t+3) | MFMA(t)
+            // Slot (t&3) is read by G0 in the second phase of stage t-1 and by G1 in the first phase of stage t: G0 refills it
+            // (tile t+4) in the second phase of stage t, G1 one phase later (tile t+3 in the first phase of stage t).
+            auto wait_keep = [&](int tiles) {          // at most `tiles` tiles (4 pieces each) of this wave stay in flight
+                if (tiles <= 0) H3_WAIT_VM(0); else if (tiles == 1) H3_WAIT_VM(4); else if (tiles == 2) H3_WAIT_VM(8); else H3_WAIT_VM(12);
+            };
+            auto mma = [&](auto fulln) {
+                constexpr bool FN = decltype(fulln)::value;
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < (FN ? 2 : 1); ++tn) {
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                    }
+            };
+            auto frags = [&](const unsigned char* st, auto fulln) {
+                constexpr bool FN = decltype(fulln)::value;
+#pragma unroll
+                for (int tn = 0; tn < (FN ? 2 : 1); ++tn) {
+                    bh[tn] = h3_frag<B_TR>(h3_addr_b<B_TR>(st, f, tn, 0));
+                    bl[tn] = h3_frag<B_TR>(h3_addr_b<B_TR>(st, f, tn, 1));
+                }
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) {
+                    ah[tm] = h3_frag<A_TR>(h3_addr_a<A_TR>(st, f, tm, 0));
+                    al[tm] = h3_frag<A_TR>(h3_addr_a<A_TR>(st, f, tm, 1));
+                }
+            };
+            auto dma = [&](int ti) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h3_glds16(gp[j] + (long)ti * gstep, lds + (ti & 3) * H3_STAGE + sdst + j * 1024);
+            };
+            auto run = [&](auto fulln) {
+                for (int t = 0; t < nkt; ++t) {
+                    if (!stB) {
+                        const int last = min(t + 3, nkt - 1);
+                        wait_keep(last - t);
+                        H3_BARRIER();
+                        if (wave_on) mma(fulln);
+                        wait_keep(last - (t + 1));
+                        H3_BARRIER();
+                        if (t + 1 < nkt && wave_on) frags(lds + ((t + 1) & 3) * H3_STAGE, fulln);
+                        if (t + 4 < nkt) dma(t + 4);
+                    } else {
+                        wait_keep(min(max(t + 2, 3), nkt - 1) - t);
+                        H3_BARRIER();
+                        if (t > 0 && wave_on) frags(lds + (t & 3) * H3_STAGE, fulln);
+                        if (t >= 1 && t + 3 < nkt) dma(t + 3);
+                        wait_keep(min(max(t + 3, 3), nkt - 1) - (t + 1));
+                        H3_BARRIER();
+                        if (wave_on) mma(fulln);
+                    }
+                }
+            };
+            if (full_n) run(std::true_type{}); else run(std::false_type{});
+        } else {
         // the two waves of a SIMD (w and w+4) issue their DMA in different halves of the stage
         if (full_n) { if (stB) H3_RUN(true, 1) else H3_RUN(true, 0) }
         else { if (stB) H3_RUN(false, 1) else H3_RUN(false, 0) }
+        }
 #undef H3_RUN
 #undef H3_STEADY
     } else {

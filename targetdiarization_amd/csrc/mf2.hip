@@ -1172,6 +1172,7 @@ int tdx_h3_gemm_variant(const void* pa, const float* sa, const void* pb, const f
     else if (variant == 3) r = tdx::launch_gemm_h3<false, EpiBias, 3>(g, 1, e, (hipStream_t)stream);
     else if (variant == 4) r = tdx::launch_gemm_h3<false, EpiBias, 4>(g, 1, e, (hipStream_t)stream);
     else if (variant == 9) r = tdx::launch_gemm_h3<false, EpiBias, 9>(g, 1, e, (hipStream_t)stream);
+    else if (variant == 5) r = tdx::launch_gemm_h3<false, EpiBias, 5>(g, 1, e, (hipStream_t)stream);
     else r = tdx::launch_gemm_h3<false, EpiBias, 0>(g, 1, e, (hipStream_t)stream);
     return r == hipSuccess ? TDX_OK : tdx::fail_hip(r, __FILE__, __LINE__);
 }

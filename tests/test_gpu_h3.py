@@ -102,3 +102,25 @@ def test_gemm_extreme_rows_and_columns(h3):
     ref = a.double() @ b.double().T
     assert float(((c.double() - ref).abs() / ref.abs().clamp_min(1e-300)).median()) < 1e-6
     assert float(((c.double() - ref).norm(dim=1) / ref.norm(dim=1)).max()) < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(1000, 300, 64), (4096, 512, 48), (3000, 2176, 512)])
+def test_pingpong_loop_is_bit_identical(h3, shape):
+    """the ping-pong main loop (diagnostic variant 5: MFMA bursts and load phases alternate between the two waves of a
+    SIMD) accumulates in the same order as the product loop: identical bits, partial edge tiles and short K included"""
+    torch.manual_seed(3)
+    m, n, k = shape
+    gv = h3.tdx_h3_gemm_variant
+    gv.restype = C.c_int
+    gv.argtypes = [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p]
+    a = torch.randn(m, k, device=dev); w = torch.randn(n, k, device=dev); bias = torch.randn(n, device=dev)
+    pa, sa = split_rows(h3, a); pb, sb = split_rows(h3, w)
+    out = []
+    for v in (0, 5):
+        c = torch.zeros(m, n, device=dev)
+        assert gv(pa.data_ptr(), sa.data_ptr(), pb.data_ptr(), sb.data_ptr(), bias.data_ptr(), c.data_ptr(), m, n, k, v, None) == 0
+        out.append(c)
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], out[1])
+    ref = a.double() @ w.double().T + bias.double()
+    assert rel(out[1], ref) < 1e-6

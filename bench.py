@@ -1,27 +1,41 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark of the hot path (BASELINE.json metric: real-time factor).
+"""bench.py — headline benchmark of the hot path (BASELINE.json metric: real-time factor of the full
+infer() pipe, 16 kHz mono, 1/2/4/8 GPU).
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path over one batch of synthetic input that is already
-resident in HBM.  Workload at N=1 = BASELINE.json configs[1]: MossFormer2 separation,
-batch of 32 synthetic 4 s / 16 kHz two-speaker mixtures (recipe of SURVEY.md §8d config 2),
-24-block model at the reference's constructor defaults, recipe (random-init) weights, fp32.
-N>1: every rank runs the same per-GPU workload on its own mixtures (independent units, weak
-scaling; no data-path collective in the separation-only configuration).
+A "step" is one pass of the hot path over one batch of synthetic audio that is already resident in HBM
+(utterances go up before the timed region; results stay on the device, DESIGN.md §5 gives the PCIe-inclusive
+rate).  The pipe per step: MossFormer2 separation (H1, 10 s windows) -> louder-stream-first swap (BS.1770 on
+the device) -> ERes2NetV2 embeddings of the separated streams + all-gather + cosine scores against a target
+embedding (H2) -> Paraformer SANM encoder on <= 30 s segments of both streams (H3), punctuation = host
+pass-through.  24-block MossFormer2 / ERes2NetV2-w24s4ep4 / 50-layer encoder at the reference's model sizes,
+recipe (random-init) weights, fp32-accurate arithmetic.
 
-Output: ONE JSON line on rank 0 (see the driver contract), plus
-  roofline     — dominant kernel (the to_hidden+to_qk fp32-MFMA GEMM, 24 launches/step):
-                 achieved = algorithmic FLOPs per launch / mean launch duration measured with
-                 HIP events recorded on the forward's stream inside the timed region.
-  cpu_baseline — the oracle (CPU restatement of the reference, pinned to it by
-                 tests/golden) timed on this host's cores on a bounded sample of the same
-                 workload (N=1, rank 0 only).
+  N = 1 (default)  BASELINE configs[3]: one 1800 s synthetic conversation = 180 windows, embeddings per 10 s
+                   window of each stream, encoder on 120 x 30 s segments.
+  N > 1            BASELINE configs[4]: the 1000 x 30 s utterance job, STRONG scaling: the job is processed in
+                   batches of --utterances-per-step (200) utterances, one step = one batch, utterance i of a
+                   batch on rank i % N, ONE all-gather (RCCL over xGMI) of the [n_i*2,192] embedding blocks per
+                   step.  `python bench.py --gpus N` without a launcher starts the N ranks itself (children via
+                   torch.distributed.run, before this process touches a GPU); under the driver's own
+                   torch.distributed.run launch it finds RANK/WORLD_SIZE and just runs.
+  --workload cfg2  BASELINE configs[1] (MossFormer2 only, 32 x 4 s) — the H1 kernel measurement of round 1.
+  --workload cfg3  BASELINE configs[2] (600 s, H1 + H2 + cosine).
+  --dry-run        N-rank plumbing on the CPU (gloo, kernels skipped, fabricated embeddings): tests only.
+
+Output: ONE JSON line on rank 0 (driver contract) with
+  roofline     — the dominant kernel (to_hidden+to_qk GEMM of MossFormer2, 24 launches per forward):
+                 algorithmic FLOPs per launch / mean launch duration from HIP events recorded around that launch
+                 on the forward's stream inside the timed region (tdx_mf2_profile_*).
+  cpu_baseline — the oracle chain (CPU restatement of the reference: separator + fbank + ERes2NetV2 + SANM
+                 encoder) timed on this host's cores on a bounded sample of the same workload (rank 0, N=1).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,15 +49,19 @@ if ROOT not in sys.path:
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak
 H3_PASSES = 3                    # f16 MFMA passes per fp32-accurate product (csrc/gemm_h3.hpp)
-# Roofline of the dominant kernel: it computes fp32-accurate products as 3 f16 MFMA passes over
-# exponent-aligned split operands, so its ceiling in ALGORITHMIC FLOP/s is the dense f16 MFMA
-# peak / 3 = 833.3 TFLOP/s.
+# Roofline of the dominant kernel: fp32-accurate products as 3 f16 MFMA passes over exponent-aligned split
+# operands, so its ceiling in ALGORITHMIC FLOP/s is the dense f16 MFMA peak / 3 = 833.3 TFLOP/s.
 PEAK_H3_TFLOPS = PEAK_F16_MFMA_TFLOPS / H3_PASSES
+DTYPE = "f32 (split-f16 x3: fp32-accurate products from three f16 MFMA passes, fp32 accumulate)"
+METRIC = "real-time factor (audio-sec/wall-sec) full infer() pipe, 16kHz mono, 1/2/4/8 GPU"
+KERNEL = ("gemm_h3_kernel<to_hidden+to_qk: split-f16 x3 MFMA over pre-split planes, ScaleNorm gain/bias epilogue "
+          "(SiLU applied by the consuming depthwise convolution)>")
+WINDOW = 160000
 
 
 def synth_mixtures(batch: int, n: int, seed: int) -> np.ndarray:
-    """SURVEY.md §8d config-2 generator: s1+s2, s_k = 0.05*N(0,1) shaped by a 4 Hz
-    raised-cosine AM envelope with random phase, clipped to [-1,1], f32."""
+    """SURVEY.md §8d generator: s1+s2, s_k = 0.05*N(0,1) shaped by a 4 Hz raised-cosine AM envelope with
+    random phase, clipped to [-1,1], f32."""
     rng = np.random.Generator(np.random.PCG64(seed))
     t = np.arange(n, dtype=np.float64) / 16000.0
     out = np.zeros((batch, n), dtype=np.float64)
@@ -68,9 +86,15 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
-def cpu_baseline(sd, wave_np, budget_windows: int):
-    """Time the oracle on the host cores over `budget_windows` windows of the workload."""
-    from oracle import mossformer2_oracle as orc          # checker / baseline leg only
+def free_port() -> int:
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+# ----------------------------------------------------------------------------------------------
+# CPU baselines (oracle = test infrastructure; only this leg of bench.py may import it)
+# ----------------------------------------------------------------------------------------------
+def cpu_baseline_h1(sd, wave_np, budget_windows: int):
+    from oracle import mossformer2_oracle as orc
     cores = host_cores()
     torch.set_num_threads(cores)
     with torch.no_grad():
@@ -89,173 +113,233 @@ def cpu_baseline(sd, wave_np, budget_windows: int):
                       f"(the reference's own batch size), oracle/mossformer2_oracle.py, torch CPU fp32, {dt:.1f}s wall"}
 
 
-def cfg5_bench(args):
-    """BASELINE configs[4] (scaled: --utterances per GPU instead of 1000 in total): utterance i lives on rank
-    i % P, each utterance = three 10 s windows through MossFormer2, ERes2NetV2 on both separated streams, ONE
-    all-gather of the [n_i*2,192] embedding blocks (RCCL over xGMI).  Host arrays in, host arrays out (the
-    boundary of `pipeline.HotPath.run`), so this number includes PCIe."""
+def cpu_baseline_pipe(sep_sd, spk_sd, asr_sd, window_np, with_asr: bool):
+    """The oracle chain on ONE 10 s window of the workload, the way the reference runs it (batch 1 per call):
+    MossFormer2 -> fbank + ERes2NetV2 on both streams + cosine -> (fbank/LFR + SANM encoder on both streams)."""
+    from oracle import eres2netv2_oracle as eo
+    from oracle import frontend_oracle as fo
+    from oracle import mossformer2_oracle as orc
+    from oracle import paraformer_oracle as po
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    stages = {}
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        y = orc.mossformer2_forward(torch.from_numpy(window_np[None]), sep_sd)[0]
+        t1 = time.perf_counter(); stages["separation"] = t1 - t0
+        print(f"[bench] cpu_baseline separation: {t1 - t0:.1f}s", file=sys.stderr, flush=True)
+        tgt = torch.randn(192)
+        for k in range(2):
+            e = eo.eres2netv2_forward(fo.sv_features(y[k])[None], spk_sd)[0]
+            orc.cosine_similarity(e.numpy(), tgt.numpy())
+        t2 = time.perf_counter(); stages["embedding"] = t2 - t1
+        print(f"[bench] cpu_baseline embedding: {t2 - t1:.1f}s", file=sys.stderr, flush=True)
+        if with_asr:
+            for k in range(2):
+                feats = fo.asr_features(y[k], torch.zeros(560), torch.ones(560))
+                po.sanm_encoder_forward(feats[None], asr_sd)
+        t3 = time.perf_counter(); stages["asr_encoder"] = t3 - t2
+        dt = t3 - t0
+    secs = window_np.shape[0] / 16000.0
+    return {"value": secs / dt, "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "sample": f"one [1,{window_np.shape[0]}] window of the same synthetic recording through the oracle chain "
+                      f"(oracle/mossformer2_oracle.py -> frontend_oracle + eres2netv2_oracle on both streams + cosine"
+                      + (" -> frontend_oracle + paraformer_oracle encoder on both streams" if with_asr else "")
+                      + f"), batch 1 per call like the reference, torch CPU fp32, {dt:.1f}s wall",
+            "stage_seconds": stages}
+
+
+# ----------------------------------------------------------------------------------------------
+# full pipe (cfg3 / cfg4 at one rank, cfg5 sharded)
+# ----------------------------------------------------------------------------------------------
+def dist_env():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def pipe_bench(args):
     import torch.distributed as dist
     from targetdiarization_amd.pipeline import HotPath, shard_indices
-    from targetdiarization_amd.weights import recipe_eres2netv2_state_dict, recipe_state_dict
-    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
-    hp = HotPath(recipe_state_dict(0, 24), recipe_eres2netv2_state_dict(0), None, cuda_device=local_rank)
-    n_total = args.utterances * world
-    mine = shard_indices(n_total, rank, world)
-    utts = [synth_mixtures(1, 480000, seed=5 + i)[0] for i in mine]
-    target = np.random.default_rng(5).standard_normal(192).astype(np.float32)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-    for _ in range(max(args.warmup, 1)):        # same shapes as the timed steps: workspaces are sized on first use
-        hp.run(utts, target, rank, world, n_total, with_asr=False)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = hp.run(utts, target, rank, world, n_total, with_asr=False)
-    barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    assert out["embeddings"].shape == (n_total * 2, 192) and np.isfinite(out["scores"]).all()
-    if rank == 0:
-        print(json.dumps({"metric": "real-time factor (audio-sec/wall-sec), hot path cfg5 (host arrays in/out)", "value": n_total * 30.0 * args.steps / dt,
-                          "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": f"BASELINE configs[4] scaled: {n_total} x 30 s utterances, utterance i on rank i % {world}, "
-                                                 "MossFormer2 (3 windows each) -> ERes2NetV2 on both streams -> all-gather of [n*2,192] embeddings "
-                                                 "-> cosine scores; recipe weights",
-                                     "utterances_per_gpu": args.utterances}}), flush=True)
-    if world > 1:
-        dist.barrier(); dist.destroy_process_group()
-
-
-def pipeline_bench(args):
-    """BASELINE configs[2]/[3] at window granularity, device-resident: every 10 s window goes
-    H1 -> (both separated streams) H2 + cosine [-> H3 encoder]; windows are independent units."""
-    from targetdiarization_amd import ops
-    from targetdiarization_amd.paraformer import ParaformerEncoder
-    from targetdiarization_amd.separator import MossFormer2Separator
-    from targetdiarization_amd.speaker import ERes2NetV2
     from targetdiarization_amd.weights import (recipe_eres2netv2_state_dict, recipe_paraformer_state_dict,
                                                recipe_state_dict)
-    dev = torch.device("cuda:0")
-    torch.cuda.set_device(dev)
-    total_s = 600 if args.workload == "cfg3" else 1800
-    T = 160000
-    nwin = total_s // 10
-    sep = MossFormer2Separator(recipe_state_dict(0, 24), device=dev)
-    spk = ERes2NetV2(recipe_eres2netv2_state_dict(0), dev)
-    asr = ParaformerEncoder(recipe_paraformer_state_dict(0, 50), dev) if args.workload == "cfg4" else None
-    wav = torch.from_numpy(synth_mixtures(nwin, T, seed=3 if args.workload == "cfg3" else 4)).to(dev)
-    target = torch.randn(192, device=dev)
-    CH = 20          # windows per launch group
-
-    ASR_CH = 180     # separated streams per encoder launch sequence (M = 180 x 167 LFR frames fills the 256 CUs)
-
-    def step():
-        t_sep = t_spk = t_asr = 0.0
-        streams = []
-        for c in range(0, nwin, CH):
-            x = wav[c:c + CH]
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e2 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            y = sep(x).reshape(-1, T)                      # [2*CH, T] separated streams
-            e1.record()
-            emb = spk(y)
-            sc = ops.cosine_scores(emb, target)
-            e2.record()
-            if asr is not None:
-                streams.append(y)
-            torch.cuda.synchronize()
-            t_sep += e0.elapsed_time(e1); t_spk += e1.elapsed_time(e2)
-        if asr is not None:                                # H3 on all separated streams, batched across the windows
-            ys = torch.cat(streams)
-            e2 = torch.cuda.Event(enable_timing=True); e3 = torch.cuda.Event(enable_timing=True)
-            e2.record()
-            for c in range(0, ys.shape[0], ASR_CH):
-                enc = asr(ys[c:c + ASR_CH])
-            e3.record()
-            torch.cuda.synchronize()
-            t_asr += e2.elapsed_time(e3)
-        return t_sep, t_spk, t_asr
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    acc = [0.0, 0.0, 0.0]
-    for _ in range(args.steps):
-        r = step()
-        acc = [a + b for a, b in zip(acc, r)]
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    S = (T - 16) // 8 + 1
-    F = 1 + (T - 400) // 160
-    fl = {"sep": sep.flops(nwin, T), "spk": spk.flops(2 * nwin, F), "asr": asr.flops(2 * nwin, (F + 5) // 6) if asr else 0.0}
-    line = {"metric": "real-time factor (audio-sec/wall-sec), hot path " + args.workload, "value": total_s * args.steps / dt,
-            "unit": "audio-s/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE {'configs[2]' if args.workload == 'cfg3' else 'configs[3]'}: {total_s} s synthetic audio as "
-                                   f"{nwin} x 10 s windows: MossFormer2 -> ERes2NetV2 on both streams + cosine"
-                                   + (" -> Paraformer encoder on both streams" if asr else "") + ", recipe weights, device-resident"},
-            "stage_ms_per_step": {"separation": acc[0] / args.steps, "embedding+cosine": acc[1] / args.steps, "asr_encoder": acc[2] / args.steps},
-            "stage_tflops": {"separation": fl["sep"] / (acc[0] / args.steps * 1e-3) / 1e12,
-                             "embedding": fl["spk"] / (acc[1] / args.steps * 1e-3) / 1e12,
-                             "asr_encoder": (fl["asr"] / (acc[2] / args.steps * 1e-3) / 1e12) if asr else None},
-            "algorithmic_flops_per_step": fl}
-    print(json.dumps(line), flush=True)
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--seconds", type=float, default=4.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--utterances", type=int, default=16, help="cfg5: 30 s utterances per GPU (BASELINE config 5 has 1000 in total)")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
-                    help="cfg2 (default, the headline config): separation only; cfg3: + ERes2NetV2 embeddings + cosine "
-                         "on 10 min of audio; cfg4: + Paraformer encoder on 30 min.  cfg3/cfg4 are extra measurements.")
-    args = ap.parse_args()
-    if args.workload == "cfg5":
-        return cfg5_bench(args)
-    if args.workload != "cfg2":
-        return pipeline_bench(args)
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    import torch.distributed as dist
+    rank, local_rank, world = dist_env()
     use_dist = world > 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
+    wl = args.workload
+    with_asr = wl != "cfg3"
+    sep_sd, spk_sd = recipe_state_dict(0, 24), recipe_eres2netv2_state_dict(0)
+    asr_sd = recipe_paraformer_state_dict(0, 50) if with_asr else None
+    hp = HotPath(sep_sd, spk_sd, asr_sd, cuda_device=local_rank, windows_per_launch=args.windows_per_launch)
+    target = torch.from_numpy(np.random.default_rng(5).standard_normal(192).astype(np.float32)).to(dev)
 
+    if wl in ("cfg3", "cfg4"):
+        total_s = 600 if wl == "cfg3" else 1800
+        nwin = total_s // 10
+        rec_np = synth_mixtures(nwin, WINDOW, seed=3 if wl == "cfg3" else 4).reshape(-1)       # one long recording
+        batches = [[torch.from_numpy(rec_np).to(dev)]]
+        n_step_total = 1
+        audio_s_per_step = float(total_s)
+        embed_segment = WINDOW
+        windows_local = nwin
+        desc = (f"BASELINE {'configs[2]' if wl == 'cfg3' else 'configs[3]'}: {total_s} s synthetic conversation = {nwin} x 10 s windows: "
+                f"MossFormer2 ({args.windows_per_launch} windows per launch) -> loudness swap -> ERes2NetV2 on every 10 s window of both streams "
+                "+ cosine vs a target embedding" + (" -> Paraformer SANM encoder on 30 s segments of both streams, punctuation pass-through" if with_asr else "")
+                + "; recipe weights, device-resident")
+        sample_window = rec_np[:WINDOW]
+    else:   # cfg5
+        n_job, per_step = args.utterances, args.utterances_per_step
+        n_batches = max(1, n_job // per_step)
+        n_used = min(n_batches, args.steps + args.warmup)
+        batches = []
+        for b in range(n_used):
+            mine = shard_indices(per_step, rank, world)
+            batches.append([torch.from_numpy(synth_mixtures(1, 3 * WINDOW, seed=5 + b * per_step + i)[0]).to(dev) for i in mine])
+        n_step_total = per_step
+        audio_s_per_step = per_step * 30.0
+        embed_segment = None
+        windows_local = 3 * len(batches[0])
+        desc = (f"BASELINE configs[4]: the {n_job} x 30 s utterance job in batches of {per_step} utterances (one step = one batch, "
+                f"utterance i of a batch on rank i % {world}; strong scaling: the batch does not grow with N): MossFormer2 (3 windows per "
+                "utterance) -> loudness swap -> ERes2NetV2 on both streams -> all-gather of the [n_i*2,192] embedding blocks (RCCL) -> cosine "
+                "scores -> Paraformer SANM encoder on both streams; recipe weights, device-resident")
+        sample_window = None
+
+    def step(k):
+        utts = batches[k % len(batches)]
+        return hp.run(utts, target, rank, world, n_step_total, with_asr=with_asr, to_host=False, embed_segment=embed_segment)
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for k in range(args.warmup):
+        out = step(k)
+        if rank == 0:
+            print(f"[bench] warmup {k + 1}/{args.warmup}", file=sys.stderr, flush=True)
+    sep = hp.ap.separater
+    launches_per_step = 24 * ((windows_local + args.windows_per_launch - 1) // args.windows_per_launch)
+    sep.profile_enable(launches_per_step * args.steps)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        out = step(args.warmup + k)
+    barrier()
+    dt = time.perf_counter() - t0
+    gemm_ms, gemm_launches = sep.profile_collect()
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    assert torch.isfinite(out["embeddings"]).all() and torch.isfinite(out["scores"]).all()
+    assert out["embeddings"].shape[0] == out["scores"].shape[0]
+
+    # one extra, untimed, instrumented step: per-stage times (events around the stages) and FLOP accounting
+    stage_ms = None
+    if rank == 0:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        utts = batches[0]
+        torch.cuda.synchronize(dev)
+        ev[0].record()
+        pairs = hp.separate_device(utts)
+        ev[1].record()
+        flat = [p[k] for p in pairs for k in (0, 1)]
+        if embed_segment:
+            clips = [s[a:a + embed_segment] for s in flat for a in range(0, int(s.shape[0]), embed_segment)]
+        else:
+            clips = flat
+        from targetdiarization_amd import ops
+        ops.cosine_scores(hp.spk.embed_device(clips), target)
+        ev[2].record()
+        if with_asr:
+            hp.encode_device(flat)
+        ev[3].record()
+        torch.cuda.synchronize(dev)
+        stage_ms = {"separation+loudness": ev[0].elapsed_time(ev[1]), "embedding+cosine": ev[1].elapsed_time(ev[2]),
+                    "asr_encoder": ev[2].elapsed_time(ev[3]) if with_asr else 0.0}
+    if use_dist:
+        dist.barrier()
+
+    if rank == 0:
+        value = audio_s_per_step * args.steps / dt
+        print(f"[bench] gpu: {dt / args.steps * 1e3:.1f} ms/step, RTF {value:.1f}", file=sys.stderr, flush=True)
+        S = (WINDOW - 16) // 8 + 1
+        F = 1 + (WINDOW - 400) // 160
+        # algorithmic FLOPs of the step on THIS rank (rank 0's shard; shards differ by at most one utterance)
+        n_win_rank = windows_local
+        fl = {"separation": sep.flops(1, WINDOW) * n_win_rank}
+        if embed_segment:
+            fl["embedding"] = hp.spk.model.flops(2 * n_win_rank, F)
+            fl["asr_encoder"] = hp.asr.flops(2 * n_win_rank // 3, ((1 + (3 * WINDOW - 400) // 160) + 5) // 6) if with_asr else 0.0
+        else:
+            F30 = 1 + (3 * WINDOW - 400) // 160
+            fl["embedding"] = hp.spk.model.flops(2 * n_win_rank // 3, F30)
+            fl["asr_encoder"] = hp.asr.flops(2 * n_win_rank // 3, (F30 + 5) // 6) if with_asr else 0.0
+        # dominant kernel: every timed launch covers min(windows_per_launch, remaining) windows; report per FULL launch
+        rows_total = args.steps * n_win_rank * S              # token rows through the GEMM over the timed region (x 24 layers)
+        gemm_flops_total = 2.0 * rows_total * 512 * 2176 * 24
+        ach = gemm_flops_total / (gemm_ms * 1e-3) / 1e12 if gemm_launches else None
+        full_rows = min(args.windows_per_launch, n_win_rank) * S
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            tj = json.load(open(tf))
+            bpr = tj.get("gemm_to_hidden_hbm_bytes_per_token_row")
+            traffic = bpr * full_rows if bpr else None
+        line = {
+            "metric": METRIC, "value": value, "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if wl == "cfg5" else "weak",
+            "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+            "config": {"workload": desc, "audio_seconds_per_step": audio_s_per_step, "windows_per_launch": args.windows_per_launch,
+                       "parallelism": f"{world} rank(s), one process per GPU, utterances sharded round-robin, full weight replica per rank"},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_H3_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (ach / PEAK_H3_TFLOPS) if ach else None, "traffic": traffic, "kernel": KERNEL,
+                         "peak_note": "algorithmic fp32-accurate FLOP/s ceiling of the kernel = dense f16 MFMA peak 2500 / 3 passes",
+                         "mfma_pipe_executed_tflops": (ach * H3_PASSES) if ach else None,
+                         "launches_timed": gemm_launches, "ms_per_launch": gemm_ms / max(gemm_launches, 1),
+                         "algorithmic_flops_per_launch": 2.0 * full_rows * 512 * 2176,
+                         "token_rows_per_full_launch": full_rows,
+                         "whole_path_tflops_per_gpu": sum(fl.values()) * args.steps / dt / 1e12,
+                         "whole_path_frac": sum(fl.values()) * args.steps / dt / 1e12 / PEAK_H3_TFLOPS},
+            "stage_ms_per_step_rank0": stage_ms,
+            "stage_tflops_rank0": {k: (fl[a] / (stage_ms[k] * 1e-3) / 1e12 if stage_ms[k] > 0 else None)
+                                   for k, a in (("separation+loudness", "separation"), ("embedding+cosine", "embedding"), ("asr_encoder", "asr_encoder"))},
+            "algorithmic_flops_per_step_rank0": fl,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            if sample_window is None:
+                sample_window = batches[0][0][:WINDOW].cpu().numpy()
+            line["cpu_baseline"] = cpu_baseline_pipe(sep_sd, spk_sd, asr_sd, sample_window, with_asr)
+            line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------
+# cfg2: MossFormer2 only (BASELINE configs[1]) — H1 kernel measurement
+# ----------------------------------------------------------------------------------------------
+def cfg2_bench(args):
+    import torch.distributed as dist
+    rank, local_rank, world = dist_env()
+    use_dist = world > 1
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
     from targetdiarization_amd.separator import MossFormer2Separator
     from targetdiarization_amd.weights import recipe_state_dict
-
     B, T = args.batch, int(round(args.seconds * 16000))
     sd = recipe_state_dict(seed=0, num_blocks=24)
     sep = MossFormer2Separator(sd, device=dev)
     wave_np = synth_mixtures(B, T, seed=2 + 1000 * rank)
-    wav = torch.from_numpy(wave_np).to(dev)           # resident in HBM before timing
+    wav = torch.from_numpy(wave_np).to(dev)
     S = (T - 16) // 8 + 1
-
     for _ in range(args.warmup):
         out = sep(wav)
     torch.cuda.synchronize(dev)
@@ -274,53 +358,139 @@ def main():
     dt = time.perf_counter() - t0
     gemm_ms, gemm_launches = sep.profile_collect()
     assert torch.isfinite(out).all()
-
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-
-    audio_s_per_step = world * B * T / 16000.0
-    value = audio_s_per_step * args.steps / dt
+    value = world * B * T / 16000.0 * args.steps / dt
     flops_step = sep.flops(B, T)
     if rank == 0:
-        print(f"[bench] gpu: {dt / args.steps * 1e3:.1f} ms/step, RTF {value:.1f}", file=sys.stderr, flush=True)
         M = B * S
-        gemm_flops = 2.0 * M * 512 * 2176          # to_hidden+to_qk: [M,512] x [512,2176]
+        gemm_flops = 2.0 * M * 512 * 2176
         ach = gemm_flops / (gemm_ms / max(gemm_launches, 1) * 1e-3) / 1e12 if gemm_launches else None
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
-            traffic = json.load(open(tf)).get("gemm_to_hidden_hbm_bytes_per_launch")
+            bpr = json.load(open(tf)).get("gemm_to_hidden_hbm_bytes_per_token_row")
+            traffic = bpr * M if bpr else None
         line = {
-            "metric": "real-time factor (audio-sec/wall-sec), MossFormer2 separation, 16kHz mono",
+            "metric": "real-time factor (audio-sec/wall-sec), MossFormer2 separation only (sub-measurement of the full pipe), 16kHz mono",
             "value": value, "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: MossFormer2 separation only, batch of {B} synthetic "
                                    f"{args.seconds:g} s 16 kHz 2-speaker mixtures per GPU, 24 blocks, recipe weights",
                        "per_gpu_batch": B, "samples_per_window": T, "frames_per_window": S,
                        "parallelism": f"{world} independent replicas (windows sharded, no collective)"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_H3_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (ach / PEAK_H3_TFLOPS) if ach else None, "traffic": traffic,
-                         "kernel": "gemm_h3_kernel<to_hidden+to_qk: split-f16 x3 MFMA over pre-split planes, ScaleNorm gain/bias epilogue (SiLU applied by the consuming depthwise convolution)>",
-                         "peak_note": "algorithmic fp32-accurate FLOP/s ceiling of the kernel = dense f16 MFMA peak 2500 / 3 passes; "
-                                      "vs the fp32-input MFMA peak (157.3) the same number is frac_vs_f32_mfma_peak",
-                         "frac_vs_f32_mfma_peak": (ach / PEAK_F32_MFMA_TFLOPS) if ach else None,
+                         "frac": (ach / PEAK_H3_TFLOPS) if ach else None, "traffic": traffic, "kernel": KERNEL,
+                         "peak_note": "algorithmic fp32-accurate FLOP/s ceiling of the kernel = dense f16 MFMA peak 2500 / 3 passes",
                          "mfma_pipe_executed_tflops": (ach * H3_PASSES) if ach else None,
                          "launches_timed": gemm_launches, "ms_per_launch": gemm_ms / max(gemm_launches, 1),
                          "algorithmic_flops_per_launch": gemm_flops,
                          "whole_path_tflops_per_gpu": flops_step * args.steps / dt / 1e12,
-                         "whole_path_frac_vs_f32_mfma_peak": flops_step * args.steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS},
+                         "whole_path_frac": flops_step * args.steps / dt / 1e12 / PEAK_H3_TFLOPS},
             "algorithmic_flops_per_step_per_gpu": flops_step,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sd, wave_np, budget_windows=4)
+            line["cpu_baseline"] = cpu_baseline_h1(sd, wave_np, budget_windows=4)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------
+# --dry-run: the N-rank plumbing on the CPU (gloo): sharding, the all-gather, the max-over-ranks clock and the
+# JSON line, with fabricated embeddings instead of kernels (tests/test_bench_launch.py)
+# ----------------------------------------------------------------------------------------------
+def dry_run(args):
+    import torch.distributed as dist
+    from targetdiarization_amd.pipeline import gather_embeddings, shard_indices
+    rank, _, world = dist_env()
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    per_step = args.utterances_per_step
+
+    def emb_of(i, stream):
+        g = torch.Generator().manual_seed(1000 * i + stream)
+        return torch.randn(192, generator=g)
+
+    def step():
+        mine = shard_indices(per_step, rank, world)
+        local = torch.stack([emb_of(i, s) for i in mine for s in (0, 1)]) if mine else torch.zeros(0, 192)
+        return gather_embeddings(local, per_step, rank, world)
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full = step()
+    if world > 1:
+        dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    ref = torch.stack([emb_of(i, s) for i in range(per_step) for s in (0, 1)])
+    ok = bool(torch.equal(full, ref))
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": per_step * 30.0 * args.steps / float(dt.item()), "unit": "audio-s/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(dt.item()) / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "none", "data": "dry-run (no kernels)",
+                          "config": {"workload": "DRY RUN: rank plumbing only (gloo, fabricated embeddings)"}, "dry_run": True,
+                          "gather_ok": ok}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(3)
+
+
+def spawn_ranks(args) -> int:
+    """`--gpus N` without a launcher: start the N ranks as CHILDREN (one process per GPU) through
+    torch.distributed.run.  This process has not touched a GPU (importing torch does not initialise HIP) and never
+    replaces itself: it waits for the children and returns their status."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default=None, choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="default: cfg4 (BASELINE configs[3], the full pipe on 1800 s) at one GPU, cfg5 (BASELINE configs[4], the "
+                         "1000-utterance job, strong scaling) at more; cfg2 = MossFormer2 only; cfg3 = 600 s without the ASR encoder")
+    ap.add_argument("--windows-per-launch", type=int, default=30, help="10 s windows per MossFormer2 launch sequence")
+    ap.add_argument("--utterances", type=int, default=1000, help="cfg5: utterances in the job")
+    ap.add_argument("--utterances-per-step", type=int, default=200, help="cfg5: utterances per step (global batch, all ranks together)")
+    ap.add_argument("--batch", type=int, default=32, help="cfg2: windows per GPU")
+    ap.add_argument("--seconds", type=float, default=4.0, help="cfg2: window length")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="rank plumbing on the CPU (gloo), no kernels")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
+    if args.dry_run:
+        return dry_run(args)
+    if args.workload is None:
+        args.workload = "cfg4" if world == 1 else "cfg5"
+    if args.workload == "cfg2":
+        return cfg2_bench(args)
+    return pipe_bench(args)
 
 
 if __name__ == "__main__":

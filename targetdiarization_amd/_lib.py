@@ -92,6 +92,40 @@ def lib():
     return _lib
 
 
+# every symbol include/tdx_test.h declares (libtdx_diag.so: test hooks, never used by the product path)
+_l = C.c_long
+DIAG_SIGNATURES = {
+    "tdx_diag_last_error": (C.c_char_p, []),
+    "tdx_h3_split_rows": (_i, [_vp, _l, _vp, _vp, _l, _i, _vp]),
+    "tdx_h3_split_kmajor": (_i, [_vp, _l, _vp, _l, _i, C.c_float, _vp]),
+    "tdx_h3_gemm_x": (_i, [_i] + [_vp] * 5 + [_i] * 3 + [_vp]),
+    "tdx_h3_gemm": (_i, [_vp] * 6 + [_i] * 3 + [_vp]),
+    "tdx_h3_gemm_variant": (_i, [_vp] * 6 + [_i] * 4 + [_vp]),
+    "tdx_linear_variant": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "tdx_fill_bench": (_i, [_i, _vp, _l, _i, _i, _vp, _vp]),
+    "tdx_fill_bench2": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
+    "tdx_fill_bench3": (_i, [_vp, _l, _i, _l, _i, _i, _i, _vp, _vp]),
+}
+DIAG_PATH = os.path.join(HERE, "libtdx_diag.so")
+_diag = None
+
+
+def diag():
+    """Load libtdx_diag.so (tests / tools only)."""
+    global _diag
+    if _diag is None:
+        if not os.path.exists(DIAG_PATH):
+            raise TdxError(f"{DIAG_PATH} not found: build it with `python -m targetdiarization_amd.build`")
+        lib()                                   # torch's HIP runtime first (see lib())
+        l = C.CDLL(DIAG_PATH)
+        for name, (res, args) in DIAG_SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _diag = l
+    return _diag
+
+
 def check(status: int):
     if status != 0:
         raise TdxError(f"libtdx status {status}: {lib().tdx_last_error().decode()}")

@@ -75,7 +75,15 @@ class AudioProcessor:
         if state_dict is not None:
             self.separater = MossFormer2Separator(state_dict, device=dev)
         else:
-            self.separater = MossFormer2Separator.from_pretrain(f"{self.separater_weights_folder}/best_model.pth", device=dev)
+            # config.yaml's `model:` block minus `_target_` = constructor kwargs (AudioProcessor.py:269-271)
+            model_args = {}
+            cfg_path = f"{self.separater_weights_folder}/config.yaml"
+            if os.path.exists(cfg_path):
+                import yaml
+                with open(cfg_path) as fh:
+                    model_args = dict((yaml.safe_load(fh) or {}).get("model", {}) or {})
+                model_args.pop("_target_", None)
+            self.separater = MossFormer2Separator.from_pretrain(f"{self.separater_weights_folder}/best_model.pth", device=dev, **model_args)
         self.separater.eval()
 
     # AudioProcessor.py:1123-1127
@@ -99,19 +107,22 @@ class AudioProcessor:
                     ends[-1] = start + n
         return list(zip(starts, ends))
 
-    def separate_windows_device(self, windows):
-        """Run the separator on a list of 1-D float32 windows; windows of equal length share one
-        batched forward (bit-compatible with B=1: the model has no cross-sample op and the
-        reference never pads a batch, mossformer_block.py:485).  Returns a list of [2,T] DEVICE tensors."""
+    def separate_windows_device(self, windows, max_batch: int = 32):
+        """Run the separator on a list of 1-D float32 windows (host arrays or device tensors); windows of
+        equal length share one batched forward (bit-compatible with B=1: the model has no cross-sample op and
+        the reference never pads a batch, mossformer_block.py:485).  Returns a list of [2,T] DEVICE tensors."""
         out = [None] * len(windows)
         by_len = {}
         for i, w in enumerate(windows):
-            by_len.setdefault(len(w), []).append(i)
+            by_len.setdefault(int(w.shape[0]), []).append(i)
         dev = self.separater.device
         for T, idxs in by_len.items():
-            for c in range(0, len(idxs), 32):                # bound the workspace: <= 32 windows / launch
-                chunk = idxs[c:c + 32]
-                x = torch.from_numpy(np.stack([windows[i] for i in chunk]).astype(np.float32, copy=False)).to(dev)
+            for c in range(0, len(idxs), max_batch):         # bound the workspace: <= max_batch windows / launch
+                chunk = idxs[c:c + max_batch]
+                if isinstance(windows[chunk[0]], torch.Tensor):
+                    x = torch.stack([windows[i] for i in chunk]).to(dev, torch.float32)
+                else:
+                    x = torch.from_numpy(np.stack([windows[i] for i in chunk]).astype(np.float32, copy=False)).to(dev)
                 y = self.separater(x)
                 for j, i in enumerate(chunk):
                     out[i] = y[j]
@@ -121,10 +132,11 @@ class AudioProcessor:
         """as above, host arrays"""
         return [t.cpu().numpy() for t in self.separate_windows_device(windows)]
 
-    def louder_first(self, pairs):
+    def louder_first_device(self, pairs):
         """The reference's LUFS compare & swap (AudioProcessor.py:949-952) for a list of device stream pairs
         [2,n]: one BS.1770 launch per distinct length (tdx_loudness), values rounded to 0.1 like meter_loudness
-        (:1123-1127).  Returns the list of (spk1, spk2) host arrays, louder stream first."""
+        (:1123-1127).  Only the [k,2] loudness values cross to the host (the rounding rule is Python's); the
+        streams stay on the device.  Returns the list of [2,n] device tensors, louder stream first."""
         from . import ops
         swap = [False] * len(pairs)
         by_len = {}
@@ -136,10 +148,14 @@ class AudioProcessor:
             l = ops.loudness(torch.cat([pairs[i] for i in idxs], 0), 16000).cpu().numpy().reshape(len(idxs), 2)
             for k, i in enumerate(idxs):
                 swap[i] = round(float(l[k, 0]), 1) < round(float(l[k, 1]), 1)
+        return [p.flip(0) if swap[i] else p for i, p in enumerate(pairs)]
+
+    def louder_first(self, pairs):
+        """host form: list of (spk1, spk2) numpy arrays"""
         res = []
-        for i, p in enumerate(pairs):
+        for p in self.louder_first_device(pairs):
             h = p.cpu().numpy()
-            res.append((h[1], h[0]) if swap[i] else (h[0], h[1]))
+            res.append((h[0], h[1]))
         return res
 
     # AudioProcessor.py:885-956

@@ -272,6 +272,7 @@ int conv_gemm_h3(const unsigned char* Ap, const float* inv_scale, const unsigned
 }  // namespace
 
 struct tdx_eres2net {
+    int device = 0;
     float* dev; std::vector<BlockW> blocks; size_t stem_w, stem_b, seg_w, seg_b; ConvW ds; AffW fuse34;
     unsigned char* dev_planes = nullptr;      // x3 planes of the stage-3/4 and layer3_ds convolution weights
     size_t consts = 0;                        // dev + consts: {2^-10, 2^-9} inverse static scales, then 8 KB of zeros (halo row)
@@ -398,8 +399,10 @@ int tdx_eres2net_create(const void* blob, size_t blob_bytes, int device, tdx_ere
     host[h->consts] = 1.0f / 1024.0f;      // activations <= 20 (ReLU20): x * 2^10 < 2^15
     host[h->consts + 1] = 1.0f / 512.0f;   // sums of two such (Res2Net chain inputs, AFF outputs) <= 40: x * 2^9 < 2^15
     if (!ok) { delete h; return tdx::fail(TDX_E_BLOB, "tdx_eres2net_create: tensor missing or wrong size: " + missing); }
-    hipError_t e = hipSetDevice(device);
+    tdx::DeviceGuard guard(device);
+    hipError_t e = guard.err;
     if (e != hipSuccess) { delete h; return tdx::fail_hip(e, __FILE__, __LINE__); }
+    h->device = device;
     e = hipMalloc(&h->dev, host.size() * sizeof(float));
     if (e != hipSuccess) { delete h; return tdx::fail_hip(e, __FILE__, __LINE__); }
     e = hipMemcpy(h->dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -494,6 +497,8 @@ int tdx_eres2net_forward(tdx_eres2net* h, const float* feat, int B, int F, float
     if (F < 9) return tdx::fail(TDX_E_INVALID, "tdx_eres2net_forward: need >= 9 fbank frames (TSTP needs >= 2 pooled frames)");
     const WsPlan wp = ws_plan(h, B, F);
     if (ws_bytes < wp.total * sizeof(float)) return tdx::fail(TDX_E_WORKSPACE, "tdx_eres2net_forward: workspace too small");
+    tdx::DeviceGuard guard(h->device);
+    if (guard.err != hipSuccess) return tdx::fail_hip(guard.err, __FILE__, __LINE__);
     hipStream_t st = (hipStream_t)stream;
     const Dims d = make_dims(F);
     const size_t rows1 = (size_t)B * 80 * F;

@@ -147,10 +147,12 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
 }  // namespace
 
 struct tdx_fbank {
+    int device = 0;
     int mode; float scale;
     float* dev; const float *Wdft, *mel, *win;
 };
 struct tdx_stft {
+    int device = 0;
     int nfft, hop, dimf, T, chunk;
     float* dev; const float *Wf, *Wi, *win, *env;
 };
@@ -192,7 +194,8 @@ int tdx_fbank_create(int mode, int device, tdx_fbank** out) {
         if (mode == 0) host[oWin + i] = (float)pow(0.5 - 0.5 * cos(2.0 * M_PI * i / (FLEN - 1)), 0.85);   // povey
         else host[oWin + i] = (float)(0.54 - 0.46 * cos(2.0 * M_PI * i / (FLEN - 1)));                     // hamming
     }
-    hipError_t e = hipSetDevice(device);
+    tdx::DeviceGuard guard(device);
+    hipError_t e = guard.err;
     if (e != hipSuccess) return tdx::fail_hip(e, __FILE__, __LINE__);
     float* dev = nullptr;
     e = hipMalloc(&dev, host.size() * sizeof(float));
@@ -200,6 +203,7 @@ int tdx_fbank_create(int mode, int device, tdx_fbank** out) {
     e = hipMemcpy(dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) { hipFree(dev); return tdx::fail_hip(e, __FILE__, __LINE__); }
     tdx_fbank* h = new tdx_fbank();
+    h->device = device;
     h->mode = mode; h->scale = mode == 1 ? 32768.0f : 1.0f; h->dev = dev; h->Wdft = dev + oW; h->mel = dev + oM; h->win = dev + oWin;
     *out = h;
     return TDX_OK;
@@ -223,6 +227,8 @@ int tdx_fbank_forward(tdx_fbank* h, const float* wav, int B, int N, float* feat,
     const int F = tdx_fbank_frames(N);
     if (B < 1 || F < 1) return tdx::fail(TDX_E_INVALID, "tdx_fbank_forward: need N >= 400 samples");
     if (ws_bytes < tdx_fbank_workspace_bytes(B, N)) return tdx::fail(TDX_E_WORKSPACE, "tdx_fbank_forward: workspace too small");
+    tdx::DeviceGuard guard(h->device);
+    if (guard.err != hipSuccess) return tdx::fail_hip(guard.err, __FILE__, __LINE__);
     hipStream_t st = (hipStream_t)stream;
     float* frames = (float*)ws_;
     float* P = frames + al((size_t)B * F * NF);
@@ -292,7 +298,8 @@ int tdx_stft_create(int n_fft, int hop, int dim_f, int dim_t, int device, tdx_st
     host.resize(oEnv + al(L), 0.f);
     for (int t = 0; t < T; ++t)
         for (int n = 0; n < N; ++n) host[oEnv + (size_t)t * hop + n] += (float)((double)host[oWin + n] * (double)host[oWin + n]);
-    hipError_t e = hipSetDevice(device);
+    tdx::DeviceGuard guard(device);
+    hipError_t e = guard.err;
     if (e != hipSuccess) return tdx::fail_hip(e, __FILE__, __LINE__);
     float* dev = nullptr;
     e = hipMalloc(&dev, host.size() * sizeof(float));
@@ -300,6 +307,7 @@ int tdx_stft_create(int n_fft, int hop, int dim_f, int dim_t, int device, tdx_st
     e = hipMemcpy(dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) { hipFree(dev); return tdx::fail_hip(e, __FILE__, __LINE__); }
     tdx_stft* h = new tdx_stft();
+    h->device = device;
     h->nfft = N; h->hop = hop; h->dimf = dim_f; h->T = T; h->chunk = chunk; h->dev = dev;
     h->Wf = dev + oWf; h->Wi = dev + oWi; h->win = dev + oWin; h->env = dev + oEnv;
     *out = h;
@@ -323,6 +331,8 @@ size_t tdx_stft_workspace_bytes(const tdx_stft* h, int R) {
 int tdx_stft_forward(tdx_stft* h, const float* x, int R, float* spec, void* ws_, size_t ws_bytes, void* stream) {
     if (!h || !x || !spec || !ws_ || R < 1) return tdx::fail(TDX_E_INVALID, "tdx_stft_forward: bad argument");
     if (ws_bytes < tdx_stft_workspace_bytes(h, R)) return tdx::fail(TDX_E_WORKSPACE, "tdx_stft_forward: workspace too small");
+    tdx::DeviceGuard guard(h->device);
+    if (guard.err != hipSuccess) return tdx::fail_hip(guard.err, __FILE__, __LINE__);
     hipStream_t st = (hipStream_t)stream;
     float* frames = (float*)ws_;
     hipLaunchKernelGGL(stft_frame_kernel, dim3(h->T, R), dim3(256), 0, st, x, h->win, frames, h->chunk, h->nfft, h->hop, h->T);
@@ -336,6 +346,8 @@ int tdx_stft_forward(tdx_stft* h, const float* x, int R, float* spec, void* ws_,
 int tdx_stft_inverse(tdx_stft* h, const float* spec, int R, float* y, void* ws_, size_t ws_bytes, void* stream) {
     if (!h || !spec || !y || !ws_ || R < 1) return tdx::fail(TDX_E_INVALID, "tdx_stft_inverse: bad argument");
     if (ws_bytes < tdx_stft_workspace_bytes(h, R)) return tdx::fail(TDX_E_WORKSPACE, "tdx_stft_inverse: workspace too small");
+    tdx::DeviceGuard guard(h->device);
+    if (guard.err != hipSuccess) return tdx::fail_hip(guard.err, __FILE__, __LINE__);
     hipStream_t st = (hipStream_t)stream;
     float* frames = (float*)ws_;
     const int K = 2 * h->dimf;

@@ -179,6 +179,7 @@ int lin3(const unsigned char* Ap, const float* As, const PfW3& W, int M, int N, 
 }  // namespace
 
 struct tdx_pfenc {
+    int device = 0;
     int L; float* dev; std::vector<PfLayer> layers; const float *ang, *anb;
     unsigned char* dev_planes = nullptr;
 };
@@ -226,7 +227,8 @@ int tdx_pfenc_create(int num_blocks, const void* blob, size_t blob_bytes, int de
     size_t ang = 0, anb = 0;
     if (ok) { ang = push(get("encoder.after_norm.weight", D), D); anb = push(get("encoder.after_norm.bias", D), D); }
     if (!ok) return tdx::fail(TDX_E_BLOB, "tdx_pfenc_create: tensor missing or wrong size: " + missing);
-    hipError_t e = hipSetDevice(device);
+    tdx::DeviceGuard guard(device);
+    hipError_t e = guard.err;
     if (e != hipSuccess) return tdx::fail_hip(e, __FILE__, __LINE__);
     float* dev = nullptr;
     e = hipMalloc(&dev, host.size() * sizeof(float));
@@ -234,6 +236,7 @@ int tdx_pfenc_create(int num_blocks, const void* blob, size_t blob_bytes, int de
     e = hipMemcpy(dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) { hipFree(dev); return tdx::fail_hip(e, __FILE__, __LINE__); }
     tdx_pfenc* h = new tdx_pfenc();
+    h->device = device;
     h->L = num_blocks; h->dev = dev; h->layers.resize(num_blocks);
     for (int l = 0; l < num_blocks; ++l) {
         const Off& o = offs[l]; PfLayer& w = h->layers[l];
@@ -294,6 +297,8 @@ int tdx_pfenc_forward(tdx_pfenc* h, const float* feats, const int* lens_host, in
     if (lens_host) for (int b = 0; b < B; ++b) if (lens_host[b] != T)
         return tdx::fail(TDX_E_INVALID, "tdx_pfenc_forward: bucket segments by length (all lens must equal T)");
     if (ws_bytes < tdx_pfenc_workspace_bytes(h, B, T)) return tdx::fail(TDX_E_WORKSPACE, "tdx_pfenc_forward: workspace too small");
+    tdx::DeviceGuard guard(h->device);
+    if (guard.err != hipSuccess) return tdx::fail_hip(guard.err, __FILE__, __LINE__);
     hipStream_t st = (hipStream_t)stream;
     const long M = (long)B * T;
     const int Sp = (T + 127) / 128 * 128;

@@ -21,7 +21,8 @@ class Fbank:
         self.device = torch.device(device)
         self._l = _lib.lib()
         h = C.c_void_p()
-        idx = self.device.index or 0
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
         _lib.check(self._l.tdx_fbank_create({"sv": 0, "asr": 1}[mode], idx, C.byref(h)))
         self._h = h
 
@@ -67,7 +68,9 @@ class BlockSTFT:
         self.device = torch.device(device)
         self._l = _lib.lib()
         h = C.c_void_p()
-        _lib.check(self._l.tdx_stft_create(n_fft, hop, dim_f, dim_t, self.device.index or 0, C.byref(h)))
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        _lib.check(self._l.tdx_stft_create(n_fft, hop, dim_f, dim_t, idx, C.byref(h)))
         self._h = h
         self.n_fft, self.hop, self.dim_f, self.dim_t = n_fft, hop, dim_f, dim_t
         self.chunk_size = int(self._l.tdx_stft_chunk_size(h))

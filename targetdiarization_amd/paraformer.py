@@ -24,7 +24,9 @@ class ParaformerEncoder:
         blob = pack_blob(state_dict)
         buf = (C.c_char * len(blob)).from_buffer_copy(blob)
         h = C.c_void_p()
-        _lib.check(self._l.tdx_pfenc_create(num_blocks, buf, len(blob), self.device.index or 0, C.byref(h)))
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        _lib.check(self._l.tdx_pfenc_create(num_blocks, buf, len(blob), idx, C.byref(h)))
         self._h = h
         self._ws = None
         self.fbank = Fbank("asr", self.device)

@@ -8,7 +8,10 @@ steps 4-6: hot loops A/B/C), restructured so that every model call is batched:
   * hot loops A/C (`get_speaker_embedding` + `cosine_similarity` per segment,
     TargetDiarization.py:581-629): all streams of equal length per launch, one scoring launch;
   * H3: the Paraformer encoder over <= 30 s segments of each stream (funasr's VAD segmentation
-    and the CIF/decoder are outside the path — SURVEY §8f N2).
+    is outside the path; the CIF predictor / decoder is `paraformer.ParaformerDecoder`, N2).
+The separated streams stay ON THE DEVICE between the stages (H1 -> loudness swap -> H2 -> H3):
+the reference crosses host<->device around every model call (AudioProcessor.py:940-946); here the
+utterances go up once and the results come down once.
 Multi-GPU (BASELINE config 5): utterance i -> rank i % P, full weight replica per rank, no
 collective on the data path except `gather_embeddings` (RCCL all-gather over xGMI of each
 rank's [n_i*2,192] block, zero-padded to the largest n_i).
@@ -46,7 +49,8 @@ def gather_embeddings(local: torch.Tensor, n_total: int, rank: int, world: int, 
 
 class HotPath:
     def __init__(self, sep_state_dict, spk_state_dict=None, asr_state_dict=None, cuda_device: int = 0,
-                 asr_segment: int = 480000, cmvn_shift=None, cmvn_scale=None):
+                 asr_segment: int = 480000, cmvn_shift=None, cmvn_scale=None, windows_per_launch: int = 32,
+                 asr_rows_per_launch: int = 32768):
         from .audio_processor import AudioProcessor
         self.device = torch.device(f"cuda:{cuda_device}")
         self.ap = AudioProcessor(is_separate_audio=True, separater_state_dict=sep_state_dict, cuda_device=cuda_device, verbose_log=False)
@@ -62,67 +66,116 @@ class HotPath:
             from .paraformer import ParaformerEncoder
             self.asr = ParaformerEncoder(asr_state_dict, self.device, cmvn_shift=cmvn_shift, cmvn_scale=cmvn_scale)
         self.asr_segment = asr_segment
+        self.windows_per_launch = windows_per_launch
+        self.asr_rows_per_launch = asr_rows_per_launch
+
+    def _dev(self, a):
+        """host array or tensor -> 1-D float32 device tensor (the one H2D of the path)"""
+        if isinstance(a, torch.Tensor):
+            return a.to(self.device, torch.float32).reshape(-1)
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32).reshape(-1)).to(self.device)
 
     # ---- H1 -------------------------------------------------------------------------------
-    def separate(self, utts):
-        """list of 1-D float32 arrays -> list of (spk1, spk2); windows of ALL utterances batched."""
-        plans = [self.ap.window_plan(len(u), 160000) for u in utts]
-        wins, owner = [], []
-        for ui, (u, plan) in enumerate(zip(utts, plans)):
-            for (s, e) in plan:
-                wins.append(u[s:e].astype(np.float32, copy=True)); owner.append(ui)
-        outs = self.ap.separate_windows_device(wins)
+    def separate_device(self, utts):
+        """list of 1-D waveforms (device tensors or host arrays) -> list of [2,n] DEVICE tensors, louder stream
+        first (AudioProcessor.py:949-952); the windows of ALL utterances are batched by length."""
+        utts = [self._dev(u) for u in utts]
+        plans = [self.ap.window_plan(int(u.shape[0]), 160000) for u in utts]
+        wins = [u[s:e] for u, plan in zip(utts, plans) for (s, e) in plan]
+        outs = self.ap.separate_windows_device(wins, self.windows_per_launch)
         pairs, k = [], 0
         for plan in plans:
-            pairs.append(torch.cat(outs[k:k + len(plan)], dim=1))       # [2, n] on the device
+            pairs.append(outs[k] if len(plan) == 1 else torch.cat(outs[k:k + len(plan)], dim=1))       # [2, n]
             k += len(plan)
-        return self.ap.louder_first(pairs)
+        return self.ap.louder_first_device(pairs)
+
+    def separate(self, utts):
+        """host form: list of (spk1, spk2) numpy arrays"""
+        res = []
+        for p in self.separate_device(utts):
+            h = p.cpu().numpy()
+            res.append((h[0], h[1]))
+        return res
 
     # ---- H2 -------------------------------------------------------------------------------
     def embed_streams(self, streams):
         return self.spk.get_speaker_embeddings(streams)
 
     # ---- H3 -------------------------------------------------------------------------------
-    def encode_streams(self, streams):
-        """Paraformer encoder outputs per stream: list of [T_i,512] arrays (segments <= 30 s,
-        equal-length segments batched)."""
+    def encode_device(self, streams):
+        """Paraformer encoder outputs per stream: list of [T_i,512] DEVICE tensors (segments <= 30 s,
+        equal-length segments batched, <= asr_rows_per_launch LFR frames per launch sequence)."""
+        streams = [self._dev(s) for s in streams]
         segs, owner = [], []
         for si, s in enumerate(streams):
-            for a in range(0, len(s), self.asr_segment):
+            for a in range(0, int(s.shape[0]), self.asr_segment):
                 seg = s[a:a + self.asr_segment]
-                if len(seg) >= 400:
+                if seg.shape[0] >= 400:
                     segs.append(seg); owner.append(si)
         outs = [None] * len(segs)
         by_len = {}
         for i, s in enumerate(segs):
-            by_len.setdefault(len(s), []).append(i)
+            by_len.setdefault(int(s.shape[0]), []).append(i)
         for n, idxs in by_len.items():
-            for c in range(0, len(idxs), 16):
-                chunk = idxs[c:c + 16]
-                x = torch.from_numpy(np.stack([segs[i] for i in chunk]).astype(np.float32, copy=False)).to(self.device)
-                y = self.asr(x).cpu().numpy()
+            rows = ((1 + (n - 400) // 160) + 5) // 6
+            step = max(1, self.asr_rows_per_launch // max(rows, 1))
+            for c in range(0, len(idxs), step):
+                chunk = idxs[c:c + step]
+                y = self.asr(torch.stack([segs[i] for i in chunk]))
                 for j, i in enumerate(chunk):
                     outs[i] = y[j]
         res = [[] for _ in streams]
         for i, si in enumerate(owner):
             res[si].append(outs[i])
-        return [np.concatenate(r, axis=0) if r else np.zeros((0, 512), np.float32) for r in res]
+        return [(r[0] if len(r) == 1 else torch.cat(r, dim=0)) if r else torch.zeros(0, 512, device=self.device) for r in res]
+
+    def encode_streams(self, streams):
+        """host form: list of [T_i,512] numpy arrays"""
+        return [t.cpu().numpy() for t in self.encode_device(streams)]
 
     # ---- whole path over a shard ------------------------------------------------------------
-    def run(self, utts, target_embedding=None, rank: int = 0, world: int = 1, n_total: int | None = None, with_asr: bool = True):
-        """utts: THIS rank's utterances (utterance i of the job lives on rank i % world).
-        Returns dict with separated streams, all-gathered embeddings [n_total*2,192] (utterance
-        order), cosine scores vs `target_embedding`, and encoder outputs of the local streams."""
+    def run(self, utts, target_embedding=None, rank: int = 0, world: int = 1, n_total: int | None = None, with_asr: bool = True,
+            to_host: bool = True, embed_segment: int | None = None):
+        """utts: THIS rank's utterances (utterance i of the job lives on rank i % world), host arrays or
+        device tensors.  Returns dict with the separated streams, the all-gathered embeddings [n_total*k,192]
+        (utterance order), cosine scores vs `target_embedding`, and encoder outputs of the local streams.
+        embed_segment: None = one embedding per separated stream (k = 2 per utterance); an integer cuts every
+        stream into pieces of that many samples (the last piece keeps the remainder if it has >= 9 fbank frames)
+        and embeds each piece — the per-window scoring of a long recording (BASELINE configs[2]/[3]); the all-gather
+        then needs every utterance to produce the same number of pieces.
+        to_host=False leaves every result on the device (the benchmark's resident-in-HBM boundary)."""
         n_total = n_total if n_total is not None else len(utts)
-        sep = self.separate(utts)
+        sep = self.separate_device(utts)
         out = {"streams": sep}
+        flat = [p[k] for p in sep for k in (0, 1)]
         if self.spk is not None:
-            flat = [s for pair in sep for s in pair]
-            local = torch.from_numpy(self.embed_streams(flat)).to(self.device) if flat else torch.zeros(0, 192, device=self.device)
-            allemb = gather_embeddings(local, n_total, rank, world)
-            out["embeddings"] = allemb.cpu().numpy()
+            if embed_segment is None:
+                clips, per = flat, 2
+            else:
+                clips = []
+                for s in flat:
+                    n = int(s.shape[0])
+                    cuts = [(a, min(a + embed_segment, n)) for a in range(0, n, embed_segment)]
+                    cuts = [(a, b) for (a, b) in cuts if b - a >= 400 + 8 * 160]
+                    clips.extend(s[a:b] for (a, b) in cuts)
+                per = (len(clips) // max(len(sep), 1)) if sep else 2
+                if world > 1 and len(clips) != per * len(sep):
+                    from ._lib import TdxError
+                    raise TdxError("embed_segment with world > 1 needs utterances of equal length")
+            local = self.spk.embed_device(clips) if clips else torch.zeros(0, 192, device=self.device)
+            allemb = gather_embeddings(local, n_total, rank, world, streams=per)
+            out["embeddings"] = allemb
             if target_embedding is not None:
-                out["scores"] = self.spk.cosine_scores(out["embeddings"], target_embedding)
+                from . import ops
+                tgt = target_embedding if isinstance(target_embedding, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(target_embedding, dtype=np.float32))
+                out["scores"] = ops.cosine_scores(allemb, tgt.to(self.device, torch.float32)) if allemb.shape[0] else torch.zeros(0, device=self.device)
         if self.asr is not None and with_asr:
-            out["encoder"] = self.encode_streams([s for pair in sep for s in pair])
+            out["encoder"] = self.encode_device(flat)
+        if to_host:                                   # the one D2H of the path
+            out["streams"] = [(p[0].cpu().numpy(), p[1].cpu().numpy()) for p in sep]
+            for k in ("embeddings", "scores"):
+                if k in out:
+                    out[k] = out[k].cpu().numpy()
+            if "encoder" in out:
+                out["encoder"] = [t.cpu().numpy() for t in out["encoder"]]
         return out

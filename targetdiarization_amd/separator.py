@@ -36,11 +36,25 @@ class MossFormer2Separator:
         self._taps = False
 
     @classmethod
-    def from_pretrain(cls, path, device="cuda:0", **kw):
+    def from_pretrain(cls, path, device="cuda:0", **model_args):
         """Load a look2hear checkpoint dict {"model_name","state_dict",...} (base_model.py:56-63)."""
-        conf = torch.load(path, map_location="cpu")
+        conf = torch.load(path, map_location="cpu", weights_only=True)     # never unpickle code from a checkpoint
         sd = conf["state_dict"] if "state_dict" in conf else conf
-        return cls(sd, device=device)
+        name = conf.get("model_name", "MossFormer2") if isinstance(conf, dict) else "MossFormer2"
+        if name != "MossFormer2":
+            raise _lib.TdxError(f"checkpoint model_name={name!r}: the MI355X build implements MossFormer2 only")
+        # config.yaml's `model:` block = constructor kwargs (AudioProcessor.py:268-271); supported: the
+        # constructor defaults (mossformer2.py:532-541) with any num_blocks
+        defaults = {"in_channels": 512, "out_channels": 512, "kernel_size": 16, "norm": "ln", "num_spks": 2,
+                    "skip_around_intra": True, "use_global_pos_enc": True, "max_length": 20000}
+        for k, v in model_args.items():
+            if k in ("num_blocks", "_target_"):
+                continue
+            if k not in defaults:
+                raise _lib.TdxError(f"unsupported MossFormer2 constructor argument {k!r}")
+            if v != defaults[k] and k != "max_length":
+                raise _lib.TdxError(f"unsupported MossFormer2 constructor argument {k}={v!r} (supported: {defaults[k]!r})")
+        return cls(sd, device=device, num_blocks=model_args.get("num_blocks"))
 
     def eval(self):
         return self

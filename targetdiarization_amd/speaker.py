@@ -21,7 +21,10 @@ class ERes2NetV2:
         blob = pack_blob(state_dict)
         buf = (C.c_char * len(blob)).from_buffer_copy(blob)
         h = C.c_void_p()
-        _lib.check(self._l.tdx_eres2net_create(buf, len(blob), self.device.index or 0, C.byref(h)))
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        with torch.cuda.device(idx):
+            _lib.check(self._l.tdx_eres2net_create(buf, len(blob), idx, C.byref(h)))
         self._h = h
         self._ws = None
         self.fbank = Fbank("sv", self.device)
@@ -39,8 +42,9 @@ class ERes2NetV2:
         if self._ws is None or self._ws.numel() < nb:
             self._ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
         out = torch.empty(B, 192, device=self.device)
-        st = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(self._l.tdx_eres2net_forward(self._h, feat.data_ptr(), B, F, out.data_ptr(), self._ws.data_ptr(), self._ws.numel(), st))
+        with torch.cuda.device(self.device):
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(self._l.tdx_eres2net_forward(self._h, feat.data_ptr(), B, F, out.data_ptr(), self._ws.data_ptr(), self._ws.numel(), st))
         return out
 
     def __call__(self, wav: torch.Tensor) -> torch.Tensor:
@@ -67,27 +71,53 @@ class SpeakerEmbedder:
         self.device = self.model.device
         self.max_batch_frames = max_batch_frames
 
+    @staticmethod
+    def _read_wav(path: str) -> np.ndarray:
+        """16 kHz mono PCM16 .wav -> float32 in [-1,1] (stdlib `wave`; anything else is outside the hot path:
+        the reference decodes through modelscope's loader)."""
+        import wave
+        with wave.open(path, "rb") as w:
+            if w.getframerate() != 16000 or w.getnchannels() != 1 or w.getsampwidth() != 2:
+                raise _lib.TdxError(f"get_speaker_embedding: {path}: need 16 kHz mono PCM16 (resampling/decoding is outside the hot path)")
+            return np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).astype(np.float32) / 32768.0
+
     # TargetASR.py:155-163
     def get_speaker_embedding(self, wav_file, embedding_model="eres2netv2_large"):
-        if not isinstance(wav_file, np.ndarray):
-            raise _lib.TdxError("get_speaker_embedding: pass a float32 numpy waveform (file I/O is outside the hot path)")
-        wav = torch.from_numpy(np.ascontiguousarray(wav_file.reshape(1, -1), dtype=np.float32))
-        return self.model(wav.to(self.device))[0].cpu().numpy().reshape(-1)
+        """wav_file: np.ndarray waveform | path of a 16 kHz mono wav | list of either (the reference hands the
+        list to the modelscope pipeline, whose 'embs' has one row per item; `.reshape(-1)` concatenates)."""
+        if isinstance(wav_file, np.ndarray):
+            items = [wav_file.reshape(-1)]
+        elif isinstance(wav_file, str):
+            items = [wav_file]
+        elif isinstance(wav_file, (list, tuple)):
+            items = list(wav_file)
+        else:
+            raise _lib.TdxError(f"get_speaker_embedding: unsupported input type {type(wav_file).__name__}")
+        wavs = [self._read_wav(it) if isinstance(it, str) else np.asarray(it, dtype=np.float32).reshape(-1) for it in items]
+        return self.get_speaker_embeddings(wavs).reshape(-1)
 
-    def get_speaker_embeddings(self, wavs):
-        """list of 1-D float32 arrays -> [len(wavs),192] array; clips of equal length are batched."""
-        out = np.zeros((len(wavs), 192), dtype=np.float32)
+    def embed_device(self, wavs):
+        """list of 1-D DEVICE tensors -> [len(wavs),192] device tensor; clips of equal length are batched.
+        Nothing crosses PCIe (hot loops A/C of TargetDiarization.infer on streams that are already resident)."""
+        out = torch.zeros(len(wavs), 192, dtype=torch.float32, device=self.device)
         by_len = {}
         for i, w in enumerate(wavs):
-            by_len.setdefault(len(w), []).append(i)
+            by_len.setdefault(int(w.shape[0]), []).append(i)
         for n, idxs in by_len.items():
             F = 1 + (n - 400) // 160
             step = max(1, self.max_batch_frames // max(F, 1))
             for c in range(0, len(idxs), step):
                 chunk = idxs[c:c + step]
-                x = torch.from_numpy(np.stack([wavs[i] for i in chunk]).astype(np.float32, copy=False)).to(self.device)
-                out[chunk] = self.model(x).cpu().numpy()
+                x = torch.stack([wavs[i] for i in chunk]).to(self.device, torch.float32)
+                out[chunk] = self.model(x)
         return out
+
+    def get_speaker_embeddings(self, wavs):
+        """list of 1-D float32 arrays -> [len(wavs),192] array; clips of equal length are batched."""
+        if not wavs:
+            return np.zeros((0, 192), dtype=np.float32)
+        dev = [torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)).to(self.device) for w in wavs]
+        return self.embed_device(dev).cpu().numpy()
 
     # TargetASR.py:144-152
     @staticmethod

@@ -45,7 +45,9 @@ class TargetASR:
             raise KeyError(f"embedding model {embedding_model!r} is not loaded")      # the reference raises KeyError here as well
         if isinstance(wav_file, np.ndarray):
             wav_file = wav_file.reshape(1, -1)
-        return self.embedding[embedding_model].get_speaker_embedding(np.asarray(wav_file, dtype=np.float32).reshape(-1))
+        elif isinstance(wav_file, str):
+            wav_file = [wav_file]
+        return self.embedding[embedding_model].get_speaker_embedding(wav_file)
 
     def get_speaker_embeddings(self, wavs, embedding_model: str = "eres2netv2_large") -> np.ndarray:
         """MI355X addition: one bucketed launch sequence for a list of clips (hot loops A/C)."""

@@ -14,14 +14,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def h3():
     from targetdiarization_amd import _lib
-    l = _lib.lib()
-    l.tdx_h3_split_rows.restype = C.c_int
-    l.tdx_h3_split_rows.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p]
-    l.tdx_h3_split_kmajor.restype = C.c_int
-    l.tdx_h3_split_kmajor.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_float, C.c_void_p]
-    l.tdx_h3_gemm_x.restype = C.c_int
-    l.tdx_h3_gemm_x.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p]
-    return l
+    return _lib.diag()          # libtdx_diag.so: the hooks of include/tdx_test.h
 
 
 dev = torch.device("cuda:0")

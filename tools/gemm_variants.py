@@ -2,7 +2,7 @@ import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from targetdiarization_amd import _lib
-l = _lib.lib()
+l = _lib.diag()
 f = l.tdx_linear_variant
 f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
 dev = torch.device("cuda:0")

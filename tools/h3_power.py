@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from targetdiarization_amd import _lib
 from tools.h3_test import split, dev
-l = _lib.lib()
+l = _lib.diag()
 gv = l.tdx_h3_gemm_variant; gv.restype = C.c_int
 gv.argtypes = [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p]
 for (m, n, k) in [(65536, 2048, 2048), (255968, 2176, 512)]:

@@ -3,7 +3,7 @@ import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from targetdiarization_amd import _lib
-l = _lib.lib()
+l = _lib.diag()
 sp = l.tdx_h3_split_rows; sp.restype = C.c_int
 sp.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p]
 gm = l.tdx_h3_gemm; gm.restype = C.c_int

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from targetdiarization_amd import _lib
 from tools.h3_test import split, dev
-l = _lib.lib()
+l = _lib.diag()
 sk = l.tdx_h3_split_kmajor; sk.restype = C.c_int
 sk.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_float, C.c_void_p]
 gx = l.tdx_h3_gemm_x; gx.restype = C.c_int

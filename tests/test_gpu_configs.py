@@ -1,0 +1,176 @@
+"""-m gpu: the BASELINE configurations beyond configs[1] at FULL model depth.
+
+  * G8: the 10 s window every config >= 3 separates (S = 19 999, 79 groups) and the config-1 clip as one window
+    (S = 17 328), 24 blocks, against outputs minted by the REFERENCE (oracle/make_goldens_10s.py);
+  * a 30 s utterance (three windows) through HotPath.run with embeddings + encoder; window 0 against G8;
+  * configs[2]/[3] call pattern (one long recording, embeddings per 10 s window, encoder per 30 s segment) at full size
+    through size-independent properties (window independence, score range, shapes);
+  * configs[4] bookkeeping with world = 2 on ONE device: both shards run through the same code path with the
+    all-gather replaced by an in-process exchange, against the world = 1 result.
+"""
+import os
+import wave as wavmod
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-4
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64).ravel(); b = np.asarray(b, dtype=np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def _g8(gold, tag):
+    fx = np.load(os.path.join(gold, "g8_mossformer2_24blk_10s.npz"))
+    return {k.split(":")[1]: fx[k] for k in fx.files if k.startswith(tag + ":")}, int(fx["stride"]), int(fx["edge"])
+
+
+def _check_g8(y, g, stride, edge, tol=REL_TOL):
+    """y [2,T] float array vs the reference fixture (strided subset, head, tail, per-stream sums and norms)"""
+    y = np.asarray(y, dtype=np.float64)
+    errs = {"strided": rel(y[:, ::stride], g["strided"]), "head": rel(y[:, :edge], g["head"]), "tail": rel(y[:, -edge:], g["tail"])}
+    for s in (0, 1):
+        errs[f"sum{s}"] = abs(y[s].sum() - g["sum"][s]) / g["abssum"][s]
+        errs[f"norm{s}"] = abs(np.sqrt((y[s] ** 2).sum()) - g["norm"][s]) / g["norm"][s]
+    assert all(e < tol for e in errs.values()), errs
+    return errs
+
+
+@pytest.fixture(scope="module")
+def sep24(sd24):
+    from targetdiarization_amd.separator import MossFormer2Separator
+    return MossFormer2Separator(sd24, device="cuda:0")
+
+
+def _mix(gold):
+    with wavmod.open(os.path.join(gold, "chat_mix.wav"), "rb") as w:
+        return np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).astype(np.float32) / 32768.0
+
+
+@pytest.mark.parametrize("tag", ["recipe_1x160000", "chat_mix_1x138634"])
+def test_10s_window_full_depth_vs_reference_golden(gold, sep24, tag):
+    from targetdiarization_amd.weights import recipe_wave
+    x = recipe_wave("g8:10s", 1, 160000)[0] if tag.startswith("recipe") else _mix(gold)
+    g, stride, edge = _g8(gold, tag)
+    y = sep24(torch.from_numpy(x)[None].cuda())[0].cpu().numpy()
+    print(tag, _check_g8(y, g, stride, edge))
+    # the same window inside a batch of 3 (the batched call pattern of configs >= 3)
+    xb = torch.from_numpy(np.stack([x[::-1].copy(), x, x * 0.5])).cuda()
+    _check_g8(sep24(xb)[1].cpu().numpy(), g, stride, edge)
+
+
+@pytest.fixture(scope="module")
+def hp24(sd24):
+    from targetdiarization_amd.pipeline import HotPath
+    from targetdiarization_amd.weights import recipe_eres2netv2_state_dict, recipe_paraformer_state_dict
+    return HotPath(sd24, recipe_eres2netv2_state_dict(0), recipe_paraformer_state_dict(0, 50), cuda_device=0, windows_per_launch=32)
+
+
+def test_30s_utterance_full_depth_pipeline(gold, hp24):
+    """one configs[4] unit: 30 s = three 10 s windows, 24 blocks, ERes2NetV2 on both streams, 50-layer encoder."""
+    from oracle import eres2netv2_oracle as eo
+    from oracle import frontend_oracle as fo
+    from oracle import mossformer2_oracle as orc
+    from targetdiarization_amd.loudness import integrated_loudness
+    from targetdiarization_amd.weights import recipe_eres2netv2_state_dict, recipe_wave
+    w0 = recipe_wave("g8:10s", 1, 160000)[0]
+    utt = np.concatenate([w0, recipe_wave("u30:b", 1, 160000)[0], recipe_wave("u30:c", 1, 160000)[0]])
+    tgt = np.random.default_rng(7).standard_normal(192).astype(np.float32)
+    res = hp24.run([utt], target_embedding=tgt)
+    a, b = res["streams"][0]
+    assert a.shape == b.shape == (480000,)
+    # louder stream first, decided on the whole 30 s streams (AudioProcessor.py:949-952)
+    assert round(integrated_loudness(a, 16000), 1) >= round(integrated_loudness(b, 16000), 1)
+    g, stride, edge = _g8(gold, "recipe_1x160000")
+    y0 = np.stack([a[:160000], b[:160000]])
+    try:
+        _check_g8(y0, g, stride, edge)
+    except AssertionError:
+        _check_g8(y0[::-1], g, stride, edge)                     # swapped by the loudness rule
+    # H2 on the 30 s streams against the oracle run on the SAME separated streams; scores against the host rule
+    spk64 = {k: v.double() for k, v in recipe_eres2netv2_state_dict(0).items()}
+    assert res["embeddings"].shape == (2, 192)
+    for i, s in enumerate((a, b)):
+        e = eo.eres2netv2_forward(fo.sv_features(torch.from_numpy(s[:80000]).double())[None], spk64)[0].numpy()
+        got = hp24.spk.get_speaker_embedding(s[:80000])
+        assert rel(got, e) < 1e-3
+        assert abs(res["scores"][i] - orc.cosine_similarity(res["embeddings"][i], tgt)) < 1e-5
+    # H3: one 30 s segment per stream -> 500 LFR frames
+    assert [e.shape for e in res["encoder"]] == [(500, 512), (500, 512)]
+    assert all(np.isfinite(e).all() for e in res["encoder"])
+    # device-resident form gives the same numbers
+    dev = hp24.run([torch.from_numpy(utt).cuda()], target_embedding=torch.from_numpy(tgt).cuda(), to_host=False)
+    assert torch.equal(dev["streams"][0].cpu(), torch.from_numpy(np.stack([a, b])))
+    assert torch.equal(dev["embeddings"].cpu(), torch.from_numpy(res["embeddings"]))
+    assert torch.equal(dev["encoder"][1].cpu(), torch.from_numpy(res["encoder"][1]))
+
+
+def _synth(nwin, seed):
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from bench import synth_mixtures
+    return synth_mixtures(nwin, 160000, seed)
+
+
+def test_config3_and_config4_full_size_properties(hp24, sep24):
+    """BASELINE configs[2] (600 s) and configs[3] (1800 s) at their stated sizes: one recording, 10 s windows batched 32 per
+    launch, one embedding per window of each stream, encoder on 30 s segments.  Size-independent properties: windows are
+    independent units (a window of the long run equals the same window alone), shapes, score range."""
+    tgt = np.random.default_rng(3).standard_normal(192).astype(np.float32)
+    rec = torch.from_numpy(_synth(180, 4).reshape(-1)).cuda()                 # 1800 s
+    out = hp24.run([rec], target_embedding=tgt, to_host=False, embed_segment=160000)
+    st = out["streams"][0]
+    assert st.shape == (2, 180 * 160000) and torch.isfinite(st).all()
+    assert out["embeddings"].shape == (360, 192) and torch.isfinite(out["embeddings"]).all()
+    sc = out["scores"].cpu().numpy()
+    assert sc.shape == (360,) and (sc >= 0).all() and (sc <= 1).all()
+    assert [tuple(e.shape) for e in out["encoder"]] == [(60 * 500, 512)] * 2 and all(torch.isfinite(e).all() for e in out["encoder"])
+    for k in (0, 77, 179):                                                    # window k alone == window k of the recording
+        y = sep24(rec[k * 160000:(k + 1) * 160000][None])[0]
+        seg = st[:, k * 160000:(k + 1) * 160000]
+        assert min(rel(seg.cpu().numpy(), y.cpu().numpy()), rel(seg.flip(0).cpu().numpy(), y.cpu().numpy())) < 1e-5
+    # configs[2]: the first 600 s without the encoder; embeddings of a window do not depend on the recording around it
+    out3 = hp24.run([rec[: 60 * 160000]], target_embedding=tgt, to_host=False, embed_segment=160000, with_asr=False)
+    assert out3["embeddings"].shape == (120, 192) and "encoder" not in out3
+    e_long = out["embeddings"].view(2, 180, 192)[:, :60]
+    e_short = out3["embeddings"].view(2, 60, 192)
+    same = rel(e_short.cpu().numpy(), e_long.cpu().numpy())
+    swapped = rel(e_short.flip(0).cpu().numpy(), e_long.cpu().numpy())       # the loudness rule is per recording
+    assert min(same, swapped) < 1e-4
+
+
+def test_config5_world2_bookkeeping_on_one_device(hp24, monkeypatch):
+    """configs[4] with world = 2, both ranks executed one after the other on this device through HotPath.run; the RCCL
+    all-gather is replaced by an in-process exchange of the padded blocks.  7 utterances (ragged shards 4 + 3) of 30 s."""
+    import torch.distributed as dist
+    from targetdiarization_amd import pipeline
+    from targetdiarization_amd.weights import recipe_wave
+    n_total, world = 7, 2
+    utts = [torch.from_numpy(recipe_wave(f"c5:{i}", 1, 480000)[0]).cuda() for i in range(n_total)]
+    tgt = torch.from_numpy(np.random.default_rng(5).standard_normal(192).astype(np.float32)).cuda()
+    ref = hp24.run(utts, tgt, to_host=False, with_asr=False)                  # world = 1
+    blocks, cur = {}, {"rank": None}
+
+    def fake_all_gather(out, buf, *a, **k):
+        blocks[cur["rank"]] = buf.clone()
+        parts = [blocks.get(r, torch.zeros_like(buf)) for r in range(world)]
+        out.copy_(torch.cat(parts, 0))
+    monkeypatch.setattr(dist, "all_gather_into_tensor", fake_all_gather)
+    res = {}
+    for r in (1, 0, 1):                                                       # rank 1 twice: its second pass sees rank 0's block
+        cur["rank"] = r
+        mine = pipeline.shard_indices(n_total, r, world)
+        res[r] = hp24.run([utts[i] for i in mine], tgt, rank=r, world=world, n_total=n_total, to_host=False, with_asr=False)
+        assert len(res[r]["streams"]) == len(mine)
+    for r in (0, 1):
+        assert res[r]["embeddings"].shape == (n_total * 2, 192)
+        assert rel(res[r]["embeddings"].cpu().numpy(), ref["embeddings"].cpu().numpy()) < 1e-5
+        assert rel(res[r]["scores"].cpu().numpy(), ref["scores"].cpu().numpy()) < 1e-5
+        for j, i in enumerate(pipeline.shard_indices(n_total, r, world)):
+            assert rel(res[r]["streams"][j].cpu().numpy(), ref["streams"][i].cpu().numpy()) < 1e-5

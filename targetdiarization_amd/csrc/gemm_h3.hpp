@@ -55,6 +55,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "devutil.hpp"
 #include "gemm.hpp"
 
 namespace tdx {
@@ -68,6 +69,7 @@ constexpr int H3_STAGE = 2 * H3_OPER;         // A then B
 constexpr int H3_NBUF = 4;
 constexpr int H3_AUX_AHEAD = 3;               // PAIRED epilogues: half row blocks of aux() operands requested ahead of the stores
 constexpr int H3_LDS = H3_NBUF * H3_STAGE;    // 128 KB
+constexpr int H3_LDS_EXTRA = 12288;           // behind the ring: TWOSEG row factors, row scales, row() values, segment factors (7 x 1 KB)
 
 struct H3Seg {
     const unsigned char* A;      // planes of the A operand
@@ -84,6 +86,16 @@ struct H3Seg {
     // split-K over a K-major operand: batch z2 covers k rows [z2*kchunk, z2*kchunk + K) clipped to ktotal
     // (kchunk = 0: unused); ktotal a multiple of 16
     int kchunk, ktotal;
+    // segmented row scales (plain row-major mode, one segment): the A planes carry one row scale per K segment of `segk`
+    // values (segk % 64 == 0, K % segk == 0; 0 = one scale per row): segment j's scales are sa + j*strideSeg.  The
+    // accumulators change their scale domain at the segment boundaries (exact powers of two), like TWOSEG.
+    int segk;
+    long strideSeg;
+    // row-major A: operand row of tile row m is m + a_shift; with a_period > 0 the rows with m % a_period == 0 read
+    // a_zero (>= 4*K zero bytes) instead — the token shift of FLASH (first half of the channels from token s-1, zero at
+    // the first token of a sample: mossformer_block.py:204-207) as the first K segment of a TWOSEG launch
+    int a_shift, a_period;
+    const unsigned char* a_zero;
 };
 
 struct H3Args {
@@ -151,7 +163,7 @@ __device__ __forceinline__ const unsigned char* h3_addr_b(const unsigned char* s
 // fragments of the following tile are read from stage buffer `nxt`; with ISSUE the wave's four
 // LDS-DMA pieces of the tile three ahead are issued (src = gp[j] + goff, dst = dmad + j KiB).
 // PH: the half of the stage in which this wave issues its DMA (the two waves of a SIMD differ).
-template <bool A_TR, bool B_TR, bool FULLN, bool NEXT, bool ISSUE, int PH>
+template <bool A_TR, bool B_TR, bool FULLN, bool NEXT, bool ISSUE, int PH, bool M16 = false>
 __device__ __forceinline__ void h3_stage(f32x16 (&acc)[4][2], f16x8 (&ah)[4], f16x8 (&al)[4], f16x8 (&bh)[2], f16x8 (&bl)[2],
                                          const unsigned char* nxt, const H3Frag& f,
                                          const unsigned char* const (&gp)[4], long goff, unsigned char* dmad) {
@@ -167,9 +179,21 @@ __device__ __forceinline__ void h3_stage(f32x16 (&acc)[4][2], f16x8 (&ah)[4], f1
     for (int tm = 0; tm < 4; ++tm) {
 #pragma unroll
         for (int tn = 0; tn < (FULLN ? 2 : 1); ++tn) {
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+            if constexpr (!M16) {
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+            } else {
+                // VARIANT 6, TIMING ONLY (wrong results): the same flops, operand registers and accumulators as six
+                // v_mfma_f32_16x16x32_f16 (16 x 16 x 32 = half the flops of 32 x 32 x 16) on the four 16 x 16 quarters
+                f32x4* q = reinterpret_cast<f32x4*>(&acc[tm][tn]);
+                q[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tm], bl[tn], q[0], 0, 0, 0);
+                q[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[tm], bh[tn], q[1], 0, 0, 0);
+                q[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tm], bh[tn], q[2], 0, 0, 0);
+                q[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[tm], bl[tn], q[3], 0, 0, 0);
+                q[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[tm], bh[tn], q[0], 0, 0, 0);
+                q[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tm], bl[tn], q[1], 0, 0, 0);
+            }
             if constexpr (ISSUE) {
                 if ((tm >> 1) == PH) h3_glds16(gp[(tm & 1) * 2 + tn] + goff, dmad + ((tm & 1) * 2 + tn) * 1024);
             }
@@ -193,13 +217,14 @@ __device__ __forceinline__ void h3_stage(f32x16 (&acc)[4][2], f16x8 (&ah)[4], f1
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm) {
         const bool dma = ISSUE && (tm >> 1) == PH;
+        constexpr int NM = M16 ? 6 : 3;
         if constexpr (FULLN) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
             if (dma) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
             if (dma) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         } else {
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
             if (dma) __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
         }
         if constexpr (NEXT) __builtin_amdgcn_sched_group_barrier(0x100, RA, 0);
@@ -243,6 +268,84 @@ template <class E, class = void> struct epi_has_rowmul { static constexpr bool v
 template <class E> struct epi_has_rowmul<E, decltype((void)&E::rowmul, void())> { static constexpr bool value = true; };
 template <class E, class = void> struct epi_has_pairmul { static constexpr bool value = false; };
 template <class E> struct epi_has_pairmul<E, decltype((void)&E::pairmul, void())> { static constexpr bool value = true; };
+// ---- split helpers (used by the PLOUT epilogue below and by the producers at the end of this file) ----
+// exponent-aligned scale of a row whose max |x| is mu: returns s = 2^(14-e) and writes inv = 2^(e-14)
+__device__ __forceinline__ float h3_row_scale(float mu, float& inv) {
+    int e = (int)((__float_as_uint(mu) >> 23) & 0xff) - 127;
+    if (mu == 0.f) e = 14;
+    e = max(-100, min(100, e));
+    inv = __uint_as_float((unsigned)(127 - 14 + e) << 23);
+    return __uint_as_float((unsigned)(127 + 14 - e) << 23);
+}
+
+// 8 consecutive k -> 16 B of hi + 16 B of lo
+__device__ __forceinline__ void h3_store_chunk(unsigned char* dst, const float* x, float s) {
+    f16x8 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float xs = x[i] * s;
+        const _Float16 a = (_Float16)xs;
+        hi[i] = a;
+        lo[i] = (_Float16)(xs - (float)a);
+    }
+    *reinterpret_cast<f16x8*>(dst) = hi;
+    *reinterpret_cast<f16x8*>(dst + 16) = lo;
+}
+
+// fused producers: a wave owns one row and lane l holds the 4 consecutive values of quad q
+// (k = 4q .. 4q+3, q = i*64 + l).  Lanes 2j and 2j+1 exchange their quads; the even lane stores
+// the hi half (16 B) of chunk j, the odd lane the lo half: consecutive lanes write consecutive
+// 16 B.  All 64 lanes must be active.
+// Each lane splits its OWN four values (packed converts: 3 VALU per value), then the lanes of a pair swap half of the result.
+struct H3Pair { uint2 hi, lo; };      // 4 x f16 each
+__device__ __forceinline__ H3Pair h3_split4(float4 v, float s) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const float xs[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+    h4 a, b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const _Float16 t = (_Float16)xs[j]; a[j] = t; b[j] = (_Float16)(xs[j] - (float)t); }
+    H3Pair r;
+    r.hi = __builtin_bit_cast(uint2, a); r.lo = __builtin_bit_cast(uint2, b);
+    return r;
+}
+__device__ __forceinline__ uint4 h3_pair16(int q, float4 v, float s) {
+    // the 16 B this lane stores: even lane = hi of the chunk's 8 k (own 4, partner's 4), odd lane = lo (partner's 4, own 4)
+    const H3Pair o = h3_split4(v, s);
+    const bool odd = q & 1;
+    const uint2 send = odd ? o.hi : o.lo;
+    uint2 recv;
+    recv.x = (unsigned)__builtin_amdgcn_mov_dpp((int)send.x, 0xB1, 0xF, 0xF, true);       // lanes 2j <-> 2j+1
+    recv.y = (unsigned)__builtin_amdgcn_mov_dpp((int)send.y, 0xB1, 0xF, 0xF, true);
+    return odd ? make_uint4(recv.x, recv.y, o.lo.x, o.lo.y) : make_uint4(o.hi.x, o.hi.y, recv.x, recv.y);
+}
+__device__ __forceinline__ void h3_emit4(unsigned char* prow, int q, float4 v, float s) {
+    *reinterpret_cast<uint4*>(prow + (q >> 1) * 32 + ((q & 1) ? 16 : 0)) = h3_pair16(q, v, s);
+}
+// the same with the store predicated per lane (the lane exchange runs for every lane): rows handled by half-waves
+__device__ __forceinline__ void h3_emit4_pred(unsigned char* prow, int q, float4 v, float s, bool ok) {
+    const uint4 w = h3_pair16(q, v, s);
+    if (ok) *reinterpret_cast<uint4*>(prow + (q >> 1) * 32 + ((q & 1) ? 16 : 0)) = w;
+}
+__device__ __forceinline__ float h3_wave_max(float v) {
+    v = h3_row16_max(v);
+    return fmaxf(fmaxf(h3_lane(v, 0), h3_lane(v, 16)), fmaxf(h3_lane(v, 32), h3_lane(v, 48)));
+}
+__device__ __forceinline__ float h3_absmax4(float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+
+
+// PLANES-OUT epilogues ("PLOUT"): the functor's values are not stored as fp32 by the lanes that hold the accumulators but
+// staged through the (then idle) LDS ring, re-read one tile row per wave and written as split-f16 ROW-MAJOR planes with an
+// exact power-of-two scale per (row, tile-wide column segment) [+ the segment's sum of squares] — the A operand format of
+// the next GEMM, without the fp32 round trip through HBM and the separate split pass.  Functor members:
+//     H3PlOut plout(int z)                     destination of batch z
+//     long prow(int z, int m)                  destination row of tile row m, or -1 (row skipped: group padding)
+//     float val(z, m, n, v, row, col[, aux])   value of element (m, n) (may also store fp32 side outputs); non-PAIRED
+//     float val2_scaled(z, m, c, av, au, row, col, aux)   PAIRED (with pairmul)
+// Column segment j = tile column index: 256 columns (128 PAIRED) -> planes bytes [j*1024, (j+1)*1024) ([j*512, ...) PAIRED)
+// of the destination row, scale[j*seg_stride + prow], ss[j*seg_stride + prow].
+struct H3PlOut { unsigned char* planes; long pitch; float* scale; float* ss; long seg_stride; };
+template <class E, class = void> struct epi_has_plout { static constexpr bool value = false; };
+template <class E> struct epi_has_plout<E, decltype((void)&E::plout, void())> { static constexpr bool value = true; };
 template <class T> __device__ __forceinline__ void h3_assume_row(const T&) {}
 __device__ __forceinline__ void h3_assume_row(long rw) { __builtin_assume(rw >= 0); }
 
@@ -319,7 +422,10 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int r = (wave & 3) * 64 + (lane >> 2) + 16 * j;
-                    gp[j] = Ag + (long)min(m0 + r, g.M - 1) * sg.lda + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
+                    const int mr = min(m0 + r, g.M - 1);
+                    const unsigned char* rowp = Ag + (long)(mr + sg.a_shift) * sg.lda;
+                    if (sg.a_period && (mr % sg.a_period) == 0) rowp = sg.a_zero;
+                    gp[j] = rowp + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
                 }
             } else {
                 gstep = 16 * sg.lda;
@@ -382,7 +488,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
     float sa_own = 0.f;
     RowT rw_own{};
     if (tid < 256) {
-        sa_own = (sl.sa + (long)zl1 * sl.strideSA + (long)zl2 * sl.strideSA2)[(long)min(m0 + tid, g.M - 1) * sl.sa_mul];
+        sa_own = (sl.sa + (long)zl1 * sl.strideSA + (long)zl2 * sl.strideSA2 + (sl.segk ? (long)(sl.K / sl.segk - 1) * sl.strideSeg : 0L))[(long)min(m0 + tid, g.M - 1) * sl.sa_mul];
         if constexpr (HAS_ROW) rw_own = epi.row(z, min(m0 + tid, g.M - 1));
         if constexpr (epi_has_rowmul<Epi>::value) sa_own *= epi.rowmul(rw_own);
     }
@@ -404,7 +510,23 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
             const float* sa1 = s1.sa + (long)(z / s1.zdiv) * s1.strideSA + (long)(z % s1.zdiv) * s1.strideSA2;
             if (tid < 256) {
                 const int m = min(m0 + tid, g.M - 1);
-                reinterpret_cast<float*>(lds + H3_LDS)[tid] = sa0[(long)m * sg0.sa_mul] / sa1[(long)m * s1.sa_mul];
+                const bool zr = sg0.a_period && (m % sg0.a_period) == 0;        // zero operand row: any finite factor will do
+                const float f0 = zr ? 1.0f : sa0[(long)(m + sg0.a_shift) * sg0.sa_mul];
+                reinterpret_cast<float*>(lds + H3_LDS)[tid] = f0 / sa1[(long)m * s1.sa_mul];
+            }
+        }
+
+        if constexpr (!TWOSEG && !A_TR) {
+            if (sg0.segk && tid < 256) {          // factors of the segment boundaries: units of segment j -> units of segment j+1
+                const float* sab = sg0.sa + (long)(z / sg0.zdiv) * sg0.strideSA + (long)zz2 * sg0.strideSA2 + (long)min(m0 + tid, g.M - 1) * sg0.sa_mul;
+                float* rft = reinterpret_cast<float*>(lds + H3_LDS + 4096);
+                const int nb = sg0.K / sg0.segk - 1;
+                float prev = sab[0];
+                for (int j = 0; j < nb; ++j) {
+                    const float nxt = sab[(long)(j + 1) * sg0.strideSeg];
+                    rft[j * 256 + tid] = prev / nxt;
+                    prev = nxt;
+                }
             }
         }
 
@@ -437,10 +559,24 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
         // stages before the MFMAs do, the accumulators are rescaled between stage nkt0-1 and stage nkt0.
 #define H3_STEADY(FULLN, PH, LIMIT, TILE0)                                                                             \
             for (; t + 4 < (LIMIT); ++t) {                                                                             \
+                if constexpr (!TWOSEG && !A_TR && !A_CONV) {                                                           \
+                    if (t == seg_bnd) {   /* segmented row scales: the accumulators go to the next segment's units */  \
+                        const float* rfl = reinterpret_cast<const float*>(lds + H3_LDS + 4096) + seg_j * 256;          \
+                        _Pragma("unroll") for (int tm = 0; tm < 4; ++tm)                                               \
+                            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                            \
+                                const f32x4 rf = *reinterpret_cast<const f32x4*>(rfl + wm * 128 + tm * 32 + 8 * j + 4 * h); \
+                                _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                        \
+                                    acc[tm][0][4 * j + i] *= rf[i];                                                    \
+                                    acc[tm][1][4 * j + i] *= rf[i];                                                    \
+                                }                                                                                      \
+                            }                                                                                          \
+                        ++seg_j; seg_bnd += seg_stp;                                                                   \
+                    }                                                                                                  \
+                }                                                                                                      \
                 if (VARIANT != 9) H3_WAIT_VM(8);                                                                       \
                 if (VARIANT != 4) H3_BARRIER();                                                                        \
                 if (wave_on)                                                                                           \
-                    h3_stage<A_TR, B_TR, FULLN, VARIANT != 2 && VARIANT != 3, VARIANT != 1 && VARIANT != 3, PH>(       \
+                    h3_stage<A_TR, B_TR, FULLN, VARIANT != 2 && VARIANT != 3, VARIANT != 1 && VARIANT != 3, PH, VARIANT == 6>( \
                         acc, ah, al, bh, bl, lds + ((t + 1) & 3) * H3_STAGE, f, gp, (long)(t + 4 - (TILE0)) * gstep,   \
                         lds + ((t + 4) & 3) * H3_STAGE + sdst);                                                        \
                 else                                                                                                   \
@@ -450,6 +586,10 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
 #define H3_RUN(FULLN, PH)                                                                                              \
         {                                                                                                              \
             int t = 0;                                                                                                 \
+            /* segmented row scales (segk >= 64, K % segk == 0: every boundary lies in the steady part of the loop) */ \
+            const int seg_stp = sg0.segk ? sg0.segk / H3_BK : 0;                                                       \
+            int seg_bnd = sg0.segk ? seg_stp : 0x7fffffff, seg_j = 0;                                                  \
+            (void)seg_stp; (void)seg_bnd; (void)seg_j;                                                                 \
             if constexpr (TWOSEG) {                                                                                    \
                 H3_STEADY(FULLN, PH, nkt0, 0)                                                                          \
                 setup(g.seg[1], gp, gstep);                                                                            \
@@ -458,11 +598,13 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
                     const H3Seg& s1 = g.seg[1];                                                                        \
                     const float* sb0 = sg0.sb + (long)(z / sg0.zdiv) * sg0.strideSB + (long)zz2 * sg0.strideSB2;       \
                     const float* sb1 = s1.sb + (long)(z / s1.zdiv) * s1.strideSB + (long)(z % s1.zdiv) * s1.strideSB2; \
-                    float cf[2];                                                                                       \
-                    _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) {                                                 \
-                        const int c = PAIRED ? (tn == 0 ? n0 + wn * 32 + l31 : g.pair_off + n0 + wn * 32 + l31)        \
-                                             : min(n0 + tn * 128 + wn * 32 + l31, g.N - 1);                            \
-                        cf[tn] = sb0[(long)c * sg0.sb_mul] / sb1[(long)c * s1.sb_mul];                                 \
+                    float cf[2] = {1.0f, 1.0f};                                                                        \
+                    if (sb0 != sb1 || sg0.sb_mul != s1.sb_mul) {   /* (same weight rows in both segments: no column factor, no load) */ \
+                        _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) {                                             \
+                            const int c = PAIRED ? (tn == 0 ? n0 + wn * 32 + l31 : g.pair_off + n0 + wn * 32 + l31)    \
+                                                 : min(n0 + tn * 128 + wn * 32 + l31, g.N - 1);                        \
+                            cf[tn] = sb0[(long)c * sg0.sb_mul] / sb1[(long)c * s1.sb_mul];                             \
+                        }                                                                                              \
                     }                                                                                                  \
                     const float* rfl = reinterpret_cast<const float*>(lds + H3_LDS);                                   \
                     _Pragma("unroll") for (int tm = 0; tm < 4; ++tm)                                                   \
@@ -589,6 +731,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
     const int lrow0 = wm * 128 + 4 * h, lcol0 = wn * 32 + l31;
     auto row_of = [&](int lr) -> RowT { if constexpr (HAS_ROW) return rwl[lr]; else return RowT{}; };
     auto epilogue = [&](auto tag) {
+        if constexpr (!epi_has_plout<Epi>::value) {
         constexpr bool CHECK = decltype(tag)::value;
         int lrow = lrow0, lcol = lcol0;
         asm volatile("" : "+v"(lrow), "+v"(lcol));
@@ -757,10 +900,202 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
                 }
             }
         }
+        }
+    };
+
+    // ---- PLOUT epilogue (see H3PlOut): phase 1 = the usual per-lane epilogue math with the value written to the staging
+    // tile T (fp32, in the ring: [256][128] PAIRED, [128][256] per half otherwise; 32-float blocks swapped on rows with
+    // bit 2 set so that the two half-waves of a store hit different banks), phase 2 = one tile row per wave (two per wave
+    // PAIRED): row max, scale, planes (16 B per lane, full lines), scale / sum of squares by lane 0.
+    auto epilogue_pl = [&](auto tag) {
+        if constexpr (epi_has_plout<Epi>::value) {
+        constexpr bool CHECK = decltype(tag)::value;
+        int lrow = lrow0, lcol = lcol0;
+        asm volatile("" : "+v"(lrow), "+v"(lcol));
+        float* const T = reinterpret_cast<float*>(lds);
+        const H3PlOut po = epi.plout(z);
+        auto rowm = [&](int lr) { return CHECK ? min(m0 + lr, g.M - 1) : m0 + lr; };
+        __syncthreads();                         // every wave has retired its last fragment reads: the ring is free
+        if constexpr (PAIRED) {
+            static_assert(epi_has_aux<Epi>::value && epi_has_pairmul<Epi>::value, "PLOUT PAIRED: gate-style functor");
+            const int c = n0 + lcol;
+            auto cc = epi.col(z, c);
+            float sc0 = sb[(long)c * sbm], sc1 = sb[(long)(g.pair_off + c) * sbm];
+            touch(cc); touch(sc0); touch(sc1);
+            { const float2 pm = epi.pairmul(cc); sc0 *= pm.x; sc1 *= pm.y; }
+            constexpr int AH = H3_AUX_AHEAD;
+            decltype(epi.aux(0, 0, 0, RowT{})) ax[AH + 1][8];
+            auto fetch = [&](int hb) {
+                int lb = lrow + (hb >> 1) * 32;
+                asm volatile("" : "+v"(lb));
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int r = (hb & 1) * 8 + r8;
+                    const int lr = lb + (r & 3) + 8 * (r >> 2);
+                    ax[hb % (AH + 1)][r8] = epi.aux(z, rowm(lr), c, row_of(lr));
+                }
+            };
+#pragma unroll
+            for (int hb = 0; hb < AH; ++hb) fetch(hb);
+#pragma unroll
+            for (int hb = 0; hb < 8; ++hb) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (hb + AH < 8) fetch(hb + AH);
+                RowT rw[8];
+                float sr[8];
+                int lb = lrow + (hb >> 1) * 32;
+                asm volatile("" : "+v"(lb));
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int r = (hb & 1) * 8 + r8;
+                    const int lr = lb + (r & 3) + 8 * (r >> 2);
+                    rw[r8] = row_of(lr);
+                    sr[r8] = sal[lr];
+                }
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) touch(ax[hb % (AH + 1)][r8]);
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int tm = hb >> 1, r = (hb & 1) * 8 + r8;
+                    const int lr = lb + (r & 3) + 8 * (r >> 2);
+                    float v = epi.val2_scaled(z, m0 + lr, c, acc[tm][0][r] * (sr[r8] * sc0), acc[tm][1][r] * (sr[r8] * sc1), rw[r8], cc, ax[hb % (AH + 1)][r8]);
+                    if (CHECK && m0 + lr >= g.M) v = 0.f;
+                    T[lr * 128 + (lcol ^ (((lr >> 2) & 1) << 5))] = v;
+                }
+            }
+            __syncthreads();
+            const int hw = lane >> 5, l32 = lane & 31;
+            unsigned char* const pbase = po.planes + (long)n0 * 4;
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int rl = wave * 32 + it * 2 + hw;
+                const int m = m0 + rl;
+                const long pr = (!CHECK || m < g.M) ? epi.prow(z, min(m, g.M - 1)) : -1L;
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(T + rl * 128 + ((4 * l32) ^ (((rl >> 2) & 1) << 5)));
+                const float4 v = make_float4(v4[0], v4[1], v4[2], v4[3]);
+                const float mu = h3_half_max(h3_absmax4(v));
+                const float q2 = h3_half_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+                float inv;
+                const float sc = h3_row_scale(mu, inv);
+                h3_emit4_pred(pbase + (pr < 0 ? 0 : pr) * po.pitch, l32, v, sc, pr >= 0);
+                if (l32 == 0 && pr >= 0) {
+                    po.scale[(long)bn * po.seg_stride + pr] = inv;
+                    if (po.ss) po.ss[(long)bn * po.seg_stride + pr] = q2;
+                }
+            }
+        } else {
+            int nn[2];
+            decltype(epi.col(0, 0)) cc[2];
+            float sc[2];
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                nn[tn] = n0 + tn * 128 + lcol;            // (PLOUT: N is a multiple of 256)
+                cc[tn] = epi.col(z, nn[tn]);
+                sc[tn] = sb[(long)nn[tn] * sbm];
+            }
+            touch(cc[0]); touch(cc[1]); touch(sc[0]); touch(sc[1]);
+            unsigned char* const pbase = po.planes + (long)n0 * 4;
+            auto phase2 = [&](int hf) {
+                __syncthreads();
+#pragma unroll 4
+                for (int it = 0; it < 16; ++it) {
+                    const int rl = wave * 16 + it;
+                    const int lr = (rl >> 6) * 128 + (2 * hf + ((rl >> 5) & 1)) * 32 + (rl & 31);
+                    const int m = m0 + lr;
+                    const long pr = (!CHECK || m < g.M) ? epi.prow(z, min(m, g.M - 1)) : -1L;      // (wave-uniform)
+                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(T + rl * 256 + ((4 * lane) ^ (((rl >> 2) & 1) << 5)));
+                    const float4 v = make_float4(v4[0], v4[1], v4[2], v4[3]);
+                    const float mu = h3_wave_max(h3_absmax4(v));
+                    float q2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                    if (po.ss) q2 = h3_wave_sum(q2);
+                    float inv;
+                    const float s_ = h3_row_scale(mu, inv);
+                    if (pr >= 0) {
+                        h3_emit4(pbase + pr * po.pitch, lane, v, s_);
+                        if (lane == 0) {
+                            po.scale[(long)bn * po.seg_stride + pr] = inv;
+                            if (po.ss) po.ss[(long)bn * po.seg_stride + pr] = q2;
+                        }
+                    }
+                }
+            };
+            if constexpr (epi_has_aux<Epi>::value) {
+                // 16 half row blocks in the order (half tile hf, tn, tm & 1, half): the aux operands of block i+1 are
+                // requested before the values of block i are formed
+                decltype(epi.aux(0, 0, 0, RowT{})) ax[2][8];
+                auto fetch = [&](int i, int set) {
+                    const int tn = (i >> 2) & 1, tm = 2 * (i >> 3) + ((i >> 1) & 1), half = i & 1;
+                    int lb = lrow + tm * 32;
+                    asm volatile("" : "+v"(lb));
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        const int r = half * 8 + r8;
+                        const int lr = lb + (r & 3) + 8 * (r >> 2);
+                        ax[set][r8] = epi.aux(z, rowm(lr), nn[tn], row_of(lr));
+                    }
+                };
+                fetch(0, 0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (i == 8) __syncthreads();             // phase 2 of the first half has read the tile
+                    if (i < 15) fetch(i + 1, (i + 1) & 1);
+                    const int tn = (i >> 2) & 1, tmh = (i >> 1) & 1, tm = 2 * (i >> 3) + tmh, half = i & 1;
+                    RowT rw[8];
+                    float sr[8];
+                    int lb = lrow + tm * 32;
+                    asm volatile("" : "+v"(lb));
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        const int r = half * 8 + r8;
+                        const int lr = lb + (r & 3) + 8 * (r >> 2);
+                        rw[r8] = row_of(lr);
+                        sr[r8] = sal[lr];
+                    }
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8) touch(ax[i & 1][r8]);
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        const int r = half * 8 + r8;
+                        const int lr = lb + (r & 3) + 8 * (r >> 2);
+                        float v = 0.f;
+                        if (!CHECK || m0 + lr < g.M) v = epi.val(z, m0 + lr, nn[tn], acc[tm][tn][r] * (sr[r8] * sc[tn]), rw[r8], cc[tn], ax[i & 1][r8]);
+                        const int rl = lr - wm * 64 - (tm - tmh) * 32;          // (wm*128 + tm*32 + x) -> wm*64 + tmh*32 + x
+                        T[rl * 256 + ((tn * 128 + lcol) ^ (((rl >> 2) & 1) << 5))] = v;
+                    }
+                    if (i == 7 || i == 15) phase2(i >> 3);
+                }
+            } else {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    if (hf) __syncthreads();
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) {
+#pragma unroll
+                        for (int tmh = 0; tmh < 2; ++tmh) {
+                            const int tm = 2 * hf + tmh;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int lr = lrow + tm * 32 + (r & 3) + 8 * (r >> 2);
+                                const RowT rw = row_of(lr);
+                                const float sr = sal[lr];
+                                float v = 0.f;
+                                if (!CHECK || m0 + lr < g.M) v = epi.val(z, m0 + lr, nn[tn], acc[tm][tn][r] * (sr * sc[tn]), rw, cc[tn]);
+                                const int rl = lr - wm * 64 - hf * 64 + 0 * tmh;      // wm*128 + (2hf+tmh)*32 + x -> wm*64 + tmh*32 + x
+                                T[rl * 256 + ((tn * 128 + lcol) ^ (((rl >> 2) & 1) << 5))] = v;
+                            }
+                        }
+                    }
+                    phase2(hf);
+                }
+            }
+        }
+        }
     };
     bool whole = m0 + 256 <= g.M;
     if constexpr (epi_has_full<Epi>::value) whole = whole && epi.full(z, m0);
-    if (whole) epilogue(std::false_type{}); else epilogue(std::true_type{});
+    if constexpr (epi_has_plout<Epi>::value) { if (whole) epilogue_pl(std::false_type{}); else epilogue_pl(std::true_type{}); }
+    else { if (whole) epilogue(std::false_type{}); else epilogue(std::true_type{}); }
 }
 
 template <bool A_TR, bool B_TR, bool PAIRED, bool TWOSEG, class Epi, int VARIANT = 0, bool A_CONV = false>
@@ -768,7 +1103,7 @@ inline hipError_t launch_gemm_h3x(H3Args g, int batches, Epi epi, hipStream_t st
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_kernel<A_TR, B_TR, PAIRED, TWOSEG, Epi, VARIANT, A_CONV>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            H3_LDS + 4096);
+                            H3_LDS + H3_LDS_EXTRA);
         attr_set = true;
     }
     g.tiles_m = (g.M + H3_BM - 1) / H3_BM;
@@ -791,10 +1126,16 @@ inline hipError_t launch_gemm_h3x(H3Args g, int batches, Epi epi, hipStream_t st
         grid = dim3(8 * ((batches + 7) / 8) * g.tiles_m * g.tiles_n, 1, 1);
     }
     if (TWOSEG && (g.seg[0].K < 64 || g.seg[1].K < 64 || g.seg[0].kchunk || g.seg[1].kchunk)) return hipErrorInvalidValue;
+    for (int i = 0; i < g.nseg; ++i) {
+        const H3Seg& sg = g.seg[i];
+        if (sg.segk && (TWOSEG || A_TR || A_CONV || sg.segk % 64 || sg.K % sg.segk || sg.K / sg.segk > 8 || sg.kchunk)) return hipErrorInvalidValue;
+        if ((sg.a_shift || sg.a_period) && (A_TR || A_CONV || (sg.a_period && !sg.a_zero))) return hipErrorInvalidValue;
+    }
+    if (epi_has_plout<Epi>::value && !PAIRED && g.N % 256) return hipErrorInvalidValue;
     if (A_CONV && (g.cv_cin < 64 || g.cv_cin % 16 || g.seg[0].K != g.cv_ntaps * g.cv_cin || !g.zero_row || batches != 1)) return hipErrorInvalidValue;
     static const int dbg = [] { const char* e = getenv("TDX_H3_DEBUG"); return e ? atoi(e) : 0; }();
     g.dbg = dbg;
-    hipLaunchKernelGGL((gemm_h3_kernel<A_TR, B_TR, PAIRED, TWOSEG, Epi, VARIANT, A_CONV>), grid, dim3(H3_THREADS), H3_LDS + 4096, st, g, epi);
+    hipLaunchKernelGGL((gemm_h3_kernel<A_TR, B_TR, PAIRED, TWOSEG, Epi, VARIANT, A_CONV>), grid, dim3(H3_THREADS), H3_LDS + H3_LDS_EXTRA, st, g, epi);
     return hipGetLastError();
 }
 
@@ -805,55 +1146,6 @@ inline hipError_t launch_gemm_h3(H3Args g, int batches, Epi epi, hipStream_t st)
 }
 
 // ---- split producers ---------------------------------------------------------------------------
-
-// exponent-aligned scale of a row whose max |x| is mu: returns s = 2^(14-e) and writes inv = 2^(e-14)
-__device__ __forceinline__ float h3_row_scale(float mu, float& inv) {
-    int e = (int)((__float_as_uint(mu) >> 23) & 0xff) - 127;
-    if (mu == 0.f) e = 14;
-    e = max(-100, min(100, e));
-    inv = __uint_as_float((unsigned)(127 - 14 + e) << 23);
-    return __uint_as_float((unsigned)(127 + 14 - e) << 23);
-}
-
-// 8 consecutive k -> 16 B of hi + 16 B of lo
-__device__ __forceinline__ void h3_store_chunk(unsigned char* dst, const float* x, float s) {
-    f16x8 hi, lo;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float xs = x[i] * s;
-        const _Float16 a = (_Float16)xs;
-        hi[i] = a;
-        lo[i] = (_Float16)(xs - (float)a);
-    }
-    *reinterpret_cast<f16x8*>(dst) = hi;
-    *reinterpret_cast<f16x8*>(dst + 16) = lo;
-}
-
-// fused producers: a wave owns one row and lane l holds the 4 consecutive values of quad q
-// (k = 4q .. 4q+3, q = i*64 + l).  Lanes 2j and 2j+1 exchange their quads; the even lane stores
-// the hi half (16 B) of chunk j, the odd lane the lo half: consecutive lanes write consecutive
-// 16 B.  All 64 lanes must be active.
-__device__ __forceinline__ void h3_emit4(unsigned char* prow, int q, float4 v, float s) {
-    float4 p;
-    p.x = __shfl_xor(v.x, 1, 64); p.y = __shfl_xor(v.y, 1, 64); p.z = __shfl_xor(v.z, 1, 64); p.w = __shfl_xor(v.w, 1, 64);
-    const bool odd = q & 1;
-    const float4 a = odd ? p : v, b = odd ? v : p;
-    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    f16x8 out;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float xs = x[i] * s;
-        const _Float16 hi = (_Float16)xs;
-        out[i] = odd ? (_Float16)(xs - (float)hi) : hi;
-    }
-    *reinterpret_cast<f16x8*>(prow + (q >> 1) * 32 + (odd ? 16 : 0)) = out;
-}
-__device__ __forceinline__ float h3_wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float h3_absmax4(float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
 
 // generic producer: fp32 rows [R][K] (pitch ld floats, K % 8 == 0, K <= 2048) -> planes (pitch 4*Kp bytes,
 // Kp = K rounded up to 16, the tail zero-filled) + scale.  One wave per row.

@@ -47,6 +47,31 @@ struct EpiHiddenT {  // silu(acc*rs[m]*g[n] + b[n])                      mossfor
     __device__ void put_scaled(float* p, float v, float, Col2 c) const { *p = f(v + c.b); }
 };
 using EpiHidden = EpiHiddenT<true>;
+// the same (pre-activation stored) with the ScaleNorm row factor formed from per-segment sums of squares that the producer of
+// the planes left behind: rs = 1 / max(sqrt(sum_j ss[j]) * C^-1/2, 1e-5)   (mossformer_block.py:52-54).
+//   SHIFT: the token-shifted row = [half 0 of token s-1 (nothing at s = 0) | half 1 of token s]
+//   else : the NSEG 128-channel segments of the gated attention output
+template <int NSEG, bool SHIFT>
+struct EpiHiddenSN {
+    const float* ss; long M; int S; float cinv; const float* g; const float* b; float* out; long ld;
+    __device__ Col2 col(int, int n) const { return Col2{g[n], b[n]}; }
+    __device__ float row(int, int m) const {
+        float s = 0.f;
+        if constexpr (SHIFT) { s = ss[M + m]; if (m % S) s += ss[m - 1]; }
+        else {
+#pragma unroll
+            for (int j = 0; j < NSEG; ++j) s += ss[(long)j * M + m];
+        }
+        return 1.0f / fmaxf(sqrtf(s) * cinv, 1e-5f);
+    }
+    __device__ float* ptr(int, int m, int n) const { return out + (long)m * (int)ld + n; }
+    __device__ long ldm() const { return ld; }
+    __device__ void put(float* p, float v, float r, Col2 c) const { *p = v * r * c.a + c.b; }
+    __device__ float rowmul(float r) const { return r; }
+    __device__ float colmul(Col2 c) const { return c.a; }
+    __device__ void put_scaled(float* p, float v, float, Col2 c) const { *p = v + c.b; }
+    __device__ void store(int, int m, int n, float v, float r, Col2 c) const { out[(long)m * (int)ld + n] = v * r * c.a + c.b; }
+};
 struct EpiQuadSim {  // relu(acc/256)^2 with key mask                       mossformer_block.py:256-262
     float* A; int G; int S; float inv_g;
     __device__ bool col(int z, int n) const { return (z % G) * 256 + n < S; }
@@ -55,6 +80,14 @@ struct EpiQuadSim {  // relu(acc/256)^2 with key mask                       moss
         float s = fmaxf(v * inv_g, 0.f);
         A[((long)z * 256 + m) * 256 + n] = keep ? s * s : 0.f;
     }
+};
+struct EpiQuadSimPl {  // the same, written as row-major planes + row scales (PLOUT): the A operand of the attention GEMM's quadratic segment
+    unsigned char* P; float* sc; int G; int S; float inv_g;
+    __device__ bool col(int z, int n) const { return (z % G) * 256 + n < S; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ float val(int, int, int, float v, EpiNone, bool keep) const { const float s = fmaxf(v * inv_g, 0.f); return keep ? s * s : 0.f; }
+    __device__ tdx::H3PlOut plout(int) const { return tdx::H3PlOut{P, 1024, sc, nullptr, 0}; }
+    __device__ long prow(int z, int m) const { return (long)z * 256 + m; }
 };
 struct EpiStore {    // plain store, per-batch stride
     float* out; long ld; long strideZ;
@@ -132,6 +165,35 @@ struct EpiAttnGatePl { // the same gate with v, u read back from the K-major spl
         o[rw + c] = t[0] * sigmoidf_acc(t[1]);
     }
 };
+struct EpiAttnGatePlOut { // the gate of EpiAttnGatePl with o written as ROW-major planes (PLOUT): one scale and one sum of squares per
+    // (token, 128-channel segment) — the A operand of to_out with segmented row scales and its ScaleNorm statistics; the
+    // fp32 o and the rowscale/split pass over it are gone.
+    const unsigned char* vuP; const float* inv; unsigned char* oP; float* os; float* oss; long M; int G; int S; int Sp; int E;
+    __device__ float col(int, int) const { return inv[0]; }
+    __device__ long row(int z, int m) const { const int b = z / G, s = (z % G) * 256 + m; return s < S ? (long)b * S + s : -1L; }
+    __device__ bool full(int z, int m0) const { return (z % G) * 256 + m0 + 256 <= S; }
+    __device__ int2 aux(int z, int m, int c, long) const {
+        const int b = z / G, s = min((z % G) * 256 + m, S - 1);
+        const int c2 = c & ~1;
+        const unsigned char* p = vuP + (long)b * Sp * (8L * E) + (long)s * (8 * E) + (c2 >> 5) * 128 + (c2 & 31) * 2 + (c & 1) * 64;
+        return make_int2(*reinterpret_cast<const int*>(p), *reinterpret_cast<const int*>(p + 4L * E));
+    }
+    __device__ float2 pairmul(float k) const { return make_float2(-1.4426950408889634f * k, k); }
+    __device__ float val2_scaled(int, int, int c, float av, float au, long rw, float, int2 w) const {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const unsigned ov = (unsigned)__builtin_amdgcn_mov_dpp(w.x, 0xB1, 0xF, 0xF, true), ou = (unsigned)__builtin_amdgcn_mov_dpp(w.y, 0xB1, 0xF, 0xF, true);
+        const unsigned sel = (c & 1) ? 0x03020706u : 0x05040100u;
+        const h2 pv = __builtin_bit_cast(h2, __builtin_amdgcn_perm(ov, (unsigned)w.x, sel));
+        const h2 pu = __builtin_bit_cast(h2, __builtin_amdgcn_perm(ou, (unsigned)w.y, sel));
+        const f2 s = f2{(float)pv[0], (float)pu[0]} + f2{(float)pv[1], (float)pu[1]};        // (v, u) / k
+        const f2 t = f2{au, av} * s;                                                         // (att_u*v, -log2(e)*att_v*u)
+        const float o = t[0] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t[1]));
+        return rw < 0 ? 0.f : o;
+    }
+    __device__ tdx::H3PlOut plout(int) const { return tdx::H3PlOut{oP, 4L * E, os, oss, M}; }
+    __device__ long prow(int z, int m) const { return row(z, m); }
+};
 struct EpiBiasPrelu { // prelu_scalar(acc + b[n])                            mossformer_block.py:405-408
     const float* b; const float* a; float* out; long ld;
     __device__ Col2 col(int, int n) const { return Col2{b[n], a[0]}; }
@@ -158,6 +220,12 @@ struct EpiBiasRelu { const float* b; float* out; long ld;
     __device__ float* ptr(int, int m, int n) const { return out + (long)m * (int)ld + n; }
     __device__ long ldm() const { return ld; }
     __device__ void put(float* p, float v, EpiNone, float c) const { *p = fmaxf(v + c, 0.f); } };
+struct EpiBiasReluPl { const float* b; unsigned char* P; float* sc;   // relu(acc + b) as row-major planes (N = 256 = one tile: whole rows)
+    __device__ float col(int, int n) const { return b[n]; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ float val(int, int, int, float v, EpiNone, float c) const { return fmaxf(v + c, 0.f); }
+    __device__ tdx::H3PlOut plout(int) const { return tdx::H3PlOut{P, 1024, sc, nullptr, 0}; }
+    __device__ long prow(int, int m) const { return m; } };
 struct EpiBias { const float* b; float* out; long ld;   // b may be null
     __device__ float col(int, int n) const { return b ? b[n] : 0.f; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
@@ -174,6 +242,15 @@ struct EpiBiasResidual { const float* b; float* x; long ld;   // x += acc + b   
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
     __device__ float aux(int, int m, int n, EpiNone) const { return x[(long)m * (int)ld + n]; }
     __device__ void store(int, int m, int n, float v, EpiNone, float c, float xo) const { x[(long)m * (int)ld + n] = xo + (v + c); } };
+struct EpiBiasResidualPl {   // the same, and the new x rows also as planes with one scale + sum of squares per (row, 256-channel half):
+    // the A operand and the ScaleNorm statistics of the next layer's to_hidden (PLOUT; N = 512 = two tiles = the two halves)
+    const float* b; float* x; long ld; unsigned char* xp; float* xs; float* xss; long M;
+    __device__ float col(int, int n) const { return b[n]; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ float aux(int, int m, int n, EpiNone) const { return x[(long)m * (int)ld + n]; }
+    __device__ float val(int, int m, int n, float v, EpiNone, float c, float xo) const { const float r = xo + (v + c); x[(long)m * (int)ld + n] = r; return r; }
+    __device__ tdx::H3PlOut plout(int) const { return tdx::H3PlOut{xp, 2048, xs, xss, M}; }
+    __device__ long prow(int, int m) const { return m; } };
 struct EpiPosEnc {   // z = acc + pe[s][n]*scale ; x = z                     mossformer2.py:490-496
     const float* pe; const float* scale; float* zout; float* x; int S;
     __device__ float col(int, int) const { return scale[0]; }
@@ -290,7 +367,7 @@ struct Plan {
     int B, T, S, G, Sp, splits, kchunk, nblk_enc, nblk_gn, nchunk1, nchunk2;
     long M;
     // offsets in floats
-    size_t E, z, x, rs, hid, vu, qk4, Abuf, slab, kvu, o, t, hraw, h, hp, hs, vuP, AbufP, Asc, qks, KvuP, kvus, uvpre, uv, f, p, c1, c2, pe, rc, rsn, stat,
+    size_t fs, xp, xs, xss, os, oss, zrow, E, z, x, rs, hid, vu, qk4, Abuf, slab, kvu, o, t, hraw, h, hp, hs, vuP, AbufP, Asc, qks, KvuP, kvus, uvpre, uv, f, p, c1, c2, pe, rc, rsn, stat,
         part, tap0, tap1, mask, total;
 };
 
@@ -332,7 +409,11 @@ bool make_plan(const tdx_mf2* h, int B, int T, Plan& P) {
     P.qks = take((size_t)3 * B * P.Sp);
     P.KvuP = take((size_t)B * QK * HID);
     P.kvus = take((size_t)B + (size_t)B * (QK * HID / 1024) + 64);
-    P.uvpre = take(M * C); P.uv = take(M * C); P.f = take(M * INNER); P.p = take(M * INNER);
+    P.uvpre = take(M * C); P.uv = take(M * C); P.f = take(M * INNER); P.fs = take(M); P.p = take(M * INNER);
+    P.xp = take(M * C);          // x as planes (2 KB per row) with per-half scales / sums of squares
+    P.xs = take(2 * M); P.xss = take(2 * M);
+    P.os = take(8 * M); P.oss = take(8 * M);      // per-(token, 128-channel segment) scales / sums of squares of the gated attention output
+    P.zrow = take(1024);         // zero planes row (token shift at the first token of a sample)
     P.c1 = take(M * INNER); P.c2 = take(M * INNER);
     P.pe = take((size_t)P.S * C); P.rc = take((size_t)P.S * 16); P.rsn = take((size_t)P.S * 16);
     P.stat = take((size_t)B * 2 + (size_t)2 * B * 256 * 2 + 64);
@@ -415,7 +496,8 @@ int attention_core(const float* qk4, const float* vu, int B, int S, int E, int s
 //   vuP : K-major planes [B][Sp][64][2][32] of v|u with the static scale st[0] (pad rows zero); vu: fp32 (gate)
 int attention_core_h3(const unsigned char* qkP, const float* qks, const unsigned char* vuP, const float* vu, const float* st,
                       int B, int S, int E, int splits, int kchunk, float* Abuf, unsigned char* AbufP, float* Asc, float* slab, float* kvu,
-                      unsigned char* KvuP, float* kvus, float* o, float* att_v, float* att_u, hipStream_t st_) {
+                      unsigned char* KvuP, float* kvus, float* o, float* att_v, float* att_u, hipStream_t st_,
+                      unsigned char* oP = nullptr, float* os = nullptr, float* oss = nullptr) {
     const int G = (S + 255) / 256, Sp = G * 256;
     const long hs = (long)B * Sp;                 // rows per head
     const unsigned char *quad_q = qkP, *lin_q = qkP + hs * 512, *quad_k = qkP + 2 * hs * 512, *lin_k = qkP + 3 * hs * 512;
@@ -425,9 +507,8 @@ int attention_core_h3(const unsigned char* qkP, const float* qks, const unsigned
         g.seg[0] = tdx::h3_seg(quad_q, sq, 512, quad_k, sk, 512, QK);
         g.seg[0].strideA = 256L * 512; g.seg[0].strideB = 256L * 512; g.seg[0].strideSA = 256; g.seg[0].strideSB = 256;
         g.nseg = 1; g.M = 256; g.N = 256;
-        EpiQuadSim e{Abuf, G, S, 1.0f / 256.0f};
+        EpiQuadSimPl e{AbufP, Asc, G, S, 1.0f / 256.0f};         // (planes straight from the epilogue: no fp32 similarity, no split pass)
         if (tdx::launch_gemm_h3x<false, false, false, false>(g, B * G, e, st_) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
-        if (tdx::launch_h3_split_rows(Abuf, 256, AbufP, Asc, (long)B * Sp, 256, st_) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
     }
     {   // Kvu[b][d][ch] = (1/S) sum_t lin_k[t][d] vu[t][ch], split over token chunks         mossformer_block.py:286,289
         // M = 128 (d): the 128 rows of waves 4-7 do not exist and those waves only feed the ring; lin_k is the A operand — once
@@ -468,7 +549,12 @@ int attention_core_h3(const unsigned char* qkP, const float* qks, const unsigned
         g.seg[1].strideB = (long)QK * 4 * 2 * E; g.seg[1].strideB2 = 0;
         g.seg[1].strideSB = 1; g.seg[1].strideSB2 = 0;
         g.nseg = 2; g.M = 256; g.N = E; g.pair_off = E;
-        if (o && !vu) {       // the model: gate operands from the planes (no fp32 copy of v|u exists)
+        if (oP) {             // the model: gate operands from the planes, o written as planes with per-segment scales / sums of squares
+            if (tdx::launch_gemm_h3x<false, true, true, true>(g, B * G, EpiAttnGatePlOut{vuP, st, oP, os, oss, (long)B * S, G, S, Sp, E}, st_) != hipSuccess)
+                return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+            return TDX_OK;
+        }
+        if (o && !vu) {       // gate operands from the planes, fp32 o
             if (tdx::launch_gemm_h3x<false, true, true, true>(g, B * G, EpiAttnGatePl{vuP, st, o, G, S, Sp, E}, st_) != hipSuccess)
                 return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
             return TDX_OK;
@@ -860,6 +946,10 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
     unsigned char* hp = (unsigned char*)(ws + P.hp);
     unsigned char *vuP = (unsigned char*)(ws + P.vuP), *AbufP = (unsigned char*)(ws + P.AbufP), *KvuP = (unsigned char*)(ws + P.KvuP);
     float *Asc = ws + P.Asc, *qks = ws + P.qks, *kvus = ws + P.kvus;
+    unsigned char *xp = (unsigned char*)(ws + P.xp), *oP = (unsigned char*)(ws + P.o), *zrow = (unsigned char*)(ws + P.zrow);
+    float *xs = ws + P.xs, *xss = ws + P.xss, *os = ws + P.os, *oss = ws + P.oss;
+    unsigned char* fP = (unsigned char*)(ws + P.f);     // f = relu(linear(x_u)) lives as planes only (1 KB per row, like the fp32 row)
+    float* fs = ws + P.fs;
     float* gnstat = stat;               // [B][2]
     float* stat1 = stat + al(2 * B);    // [B][256][2]
     float* stat2 = stat1 + (size_t)B * 512;
@@ -876,17 +966,27 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
                        (const float*)nullptr, (const float*)nullptr, t, M, S);
     LAUNCH_CHECK();
     TRY(split_linear_h3(t, C, hp, hs, (int)M, h->hWenc, C, C, EpiPosEnc{pe, h->pe_scale, z, x, S}, st));
+    // x as planes with per-half scales and sums of squares: inside the stack the producers of x keep them up to date
+    if (hipMemsetAsync(zrow, 0, 4096, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    hipLaunchKernelGGL(xplanes_kernel, dim3((unsigned)((2 * M + 3) / 4)), dim3(256), 0, st, x, xp, xs, xss, M);
+    LAUNCH_CHECK();
 
     for (int l = 0; l < h->L; ++l) {
         const LayerW& w = h->layers[l];
         // ================= FLASH_ShareA_FFConvM  (mossformer_block.py:191-220)
-        // token shift + ScaleNorm statistics + split-f16 planes of the shifted row, one pass over x
-        hipLaunchKernelGGL((rowscale_split_kernel<C, true>), rows4(M), dim3(256), 0, st, x, rs, hp, hs, M, S);
-        LAUNCH_CHECK();
+        // token shift + ScaleNorm: the GEMM reads the planes of x as TWO K segments — channels 0..255 from the row above
+        // (zero row at the first token of a sample), channels 256..511 from the row itself — each with its own row scale;
+        // the ScaleNorm factor comes from the halves' sums of squares (no pass over x)
         {
             const bool prof = h->ev_used < h->ev0.size();
             if (prof) hipEventRecord(h->ev0[h->ev_used], st);
-            TRY(linear_h3(hp, hs, (int)M, w.hWhq, HQ, C, EpiHiddenT<false>{rs, w.ghq, w.bhq, hid, HQ}, st));    // (SiLU in conv17)
+            tdx::H3Args g{};
+            g.seg[0] = tdx::h3_seg(xp, xs, 4L * C, w.hWhq.p, w.hWhq.s, 4L * C, C / 2);
+            g.seg[0].a_shift = -1; g.seg[0].a_period = S; g.seg[0].a_zero = zrow;
+            g.seg[1] = tdx::h3_seg(xp + 2 * C, xs + M, 4L * C, w.hWhq.p + 2 * C, w.hWhq.s, 4L * C, C / 2);
+            g.nseg = 2; g.M = (int)M; g.N = HQ;
+            EpiHiddenSN<2, true> e{xss, M, S, 0.044194173824159216f, w.ghq, w.bhq, hid, HQ};       // (SiLU in conv17)
+            if (tdx::launch_gemm_h3x<false, false, false, true>(g, 1, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
             if (prof) { hipEventRecord(h->ev1[h->ev_used], st); h->ev_used++; }
         }
         {
@@ -901,18 +1001,31 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
             TRY(launch_conv17<3>(q, B, st));          // the four heads as planes
         }
         TRY(attention_core_h3((const unsigned char*)qk4, qks, vuP, nullptr, w.st, B, S, 1024, P.splits, P.kchunk, Abuf, AbufP, Asc, slab, kvu, KvuP,
-                              kvus, o, nullptr, nullptr, st));
-        hipLaunchKernelGGL((rowscale_split_kernel<1024, false>), rows4(M), dim3(256), 0, st, o, rs, hp, hs, M, S);
-        LAUNCH_CHECK();
-        TRY(linear_h3(hp, hs, (int)M, w.hWo, C, 1024, EpiHiddenT<false>{rs, w.go, w.bo, t, C}, st));
+                              kvus, nullptr, nullptr, nullptr, st, oP, os, oss));
+        {   // to_out: A = the planes of o with one row scale per 128-channel segment; ScaleNorm from the segments' sums of squares
+            tdx::H3Args g{};
+            g.seg[0] = tdx::h3_seg(oP, os, 4L * 1024, w.hWo.p, w.hWo.s, 4L * 1024, 1024);
+            g.seg[0].segk = 128; g.seg[0].strideSeg = M;
+            g.nseg = 1; g.M = (int)M; g.N = C;
+            EpiHiddenSN<8, false> e{oss, M, S, 0.03125f, w.go, w.bo, t, C};
+            if (tdx::launch_gemm_h3x<false, false, false, false>(g, 1, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+        }
         {
             Conv17Args a{};
             a.in = t; a.ld_in = C; a.col0 = 0; a.wT = w.cw_o; a.C = C; a.out = x; a.ld_out = C; a.S = S; a.Sp = Sp; a.silu_in = 1;
+            a.xp = xp; a.xs = xs; a.xs_stride = M;       // the new x also as planes (per-half scales): W1's A operand
             TRY(launch_conv17<1>(a, B, st));
         }
         if (h->taps && l == 0) hipMemcpyAsync(ws + P.tap0, x, M * C * sizeof(float), hipMemcpyDeviceToDevice, st);
         // ================= GatedFSMNBlockDilated  (mossformer_block.py:419-425)
-        TRY(split_linear_h3(x, C, hp, hs, (int)M, w.hW1, INNER, C, EpiBiasPrelu{w.b1, w.a1, hraw, INNER}, st));
+        {
+            tdx::H3Args g{};
+            g.seg[0] = tdx::h3_seg(xp, xs, 4L * C, w.hW1.p, w.hW1.s, 4L * C, C);
+            g.seg[0].segk = 256; g.seg[0].strideSeg = M;
+            g.nseg = 1; g.M = (int)M; g.N = INNER;
+            if (tdx::launch_gemm_h3x<false, false, false, false>(g, 1, EpiBiasPrelu{w.b1, w.a1, hraw, INNER}, st) != hipSuccess)
+                return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+        }
         hipLaunchKernelGGL((layernorm_kernel<INNER, true>), rows4(M), dim3(256), 0, st, hraw, w.ln1g, w.ln1b, hh, (float*)nullptr, M, 1e-5f,
                            hp, hs);
         LAUNCH_CHECK();
@@ -920,15 +1033,16 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
         {
             Conv17Args a{};
             a.in = uvpre; a.ld_in = C; a.col0 = 0; a.wT = w.cw_uv; a.C = C; a.out = uv; a.ld_out = C; a.S = S; a.Sp = Sp;
+            a.xp = hp; a.xs = hs;                          // x_u (channels 0..255) also as planes: the A operand of fsmn.linear
             TRY(launch_conv17<0>(a, B, st));
         }
-        TRY(split_linear_h3(uv, C, hp, hs, (int)M, w.hWl, INNER, INNER, EpiBiasRelu{w.bl, f, INNER}, st));
-        TRY(split_linear_h3(f, INNER, hp, hs, (int)M, w.hWp, INNER, INNER, EpiBias{nullptr, p, INNER}, st));
+        TRY(linear_h3(hp, hs, (int)M, w.hWl, INNER, INNER, EpiBiasReluPl{w.bl, fP, fs}, st));       // f = relu(.) as planes
+        TRY(linear_h3(fP, fs, (int)M, w.hWp, INNER, INNER, EpiBias{nullptr, p, INNER}, st));
         TRY(ddn_core(p, B, S, w.w1T, w.w2T, w.ing, w.inb, w.pre, c1, c2, stat1, stat2, part, st));
         hipLaunchKernelGGL(fsmn_tail_kernel, rows4(M), dim3(256), 0, st, c2, stat2, w.ing + INNER, w.inb + INNER, w.pre + INNER, uv, hh,
                            w.ln2g, w.ln2b, hp, hs, M, S);
         LAUNCH_CHECK();
-        TRY(linear_h3(hp, hs, (int)M, w.hW2, C, INNER, EpiBiasResidual{w.b2, x, C}, st));
+        TRY(linear_h3(hp, hs, (int)M, w.hW2, C, INNER, EpiBiasResidualPl{w.b2, x, C, xp, xs, xss, M}, st));    // x += ..., and its planes / statistics
         if (h->taps && l == 0) hipMemcpyAsync(ws + P.tap1, x, M * C * sizeof(float), hipMemcpyDeviceToDevice, st);
     }
 

@@ -189,6 +189,23 @@ __global__ __launch_bounds__(256) void rowscale_split_kernel(const float* __rest
     }
 }
 
+// x[M][512] -> row-major planes with one scale and one sum of squares per (row, 256-channel half): the layout the
+// GEMM epilogues / conv17<1> keep x in (xs[h*M + m], xss[h*M + m]); one wave per (row, half).  Used once per forward
+// (x after the positional encoding); inside the stack the producers write the planes themselves.
+__global__ __launch_bounds__(256) void xplanes_kernel(const float* __restrict__ x, unsigned char* __restrict__ xp, float* __restrict__ xs,
+                                                       float* __restrict__ xss, long M) {
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= 2 * M) return;
+    const long m = i >> 1;
+    const int hf = (int)(i & 1), lane = threadIdx.x & 63;
+    const float4 v = *reinterpret_cast<const float4*>(x + m * 512 + hf * 256 + lane * 4);
+    const float q2 = wave_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+    float inv;
+    const float sc = h3_row_scale(h3_wave_max(h3_absmax4(v)), inv);
+    h3_emit4(xp + m * 2048, hf * 64 + lane, v, sc);
+    if (lane == 0) { xs[(long)hf * M + m] = inv; xss[(long)hf * M + m] = q2; }
+}
+
 // ---------------------------------------------------------------------------------------
 // DilatedDenseNet (fsmn.py:76-111), token-major, one thread per channel, 256 threads.
 //  conv1: c1 = dwconv_{k=39,dil=1,pad=19}(p)                         (+ IN statistics)

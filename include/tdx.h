@@ -195,6 +195,15 @@ size_t tdx_loudness_workspace_bytes(int B, long N, int rate);
 int tdx_loudness(const float* wav_dev, int B, long N, int rate, double* lufs_dev, void* workspace,
                  size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * N3   rational polyphase resampler — replaces AudioProcessor.audio_resample  AudioProcessor.py:549-569
+ *      (librosa.resample, third-party; parity unpinned: the filter is the caller's — the Python host designs a
+ *      Kaiser-windowed sinc like scipy.signal.resample_poly).  x_dev [C][n_in] -> y_dev [C][n_out],
+ *      n_out = ceil(n_in*up/down); h_dev: 2*half+1 taps with DC gain `up`; the filter delay is removed.
+ * ---------------------------------------------------------------------------------- */
+int tdx_resample_poly(const float* x_dev, long n_in, int C, int up, int down, const float* h_dev, int half,
+                      float* y_dev, long n_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,7 @@ SIGNATURES = {
     "tdx_cosine_scores": (_i, [_fp, _fp, _i, _i, _fp, _vp]),
     "tdx_loudness_workspace_bytes": (_sz, [_i, C.c_long, _i]),
     "tdx_loudness": (_i, [_fp, _i, C.c_long, _i, _vp, _vp, _sz, _vp]),
+    "tdx_resample_poly": (_i, [_fp, C.c_long, _i, _i, _i, _fp, _i, _fp, C.c_long, _vp]),
 }
 
 

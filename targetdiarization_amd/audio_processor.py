@@ -5,9 +5,14 @@ the same `separate_speaker` contract (:885-956).  What differs is *how* it runs:
 of equal length are batched into ONE device launch sequence (the reference loops with
 batch = 1), on the MI355X-native MossFormer2 (libtdx.so).
 
-Out of scope here: MDX ONNX net, enhancer, Apollo restorer, resampling,
-file I/O — those flags are accepted and degrade to "module skipped" exactly like the
-reference does when a package is disabled.
+`denoise_vocal` (:601-713) keeps the reference's outer 15 s / 1 s-margin chunker and the block plan of
+`process_audio_chunk` (:605-643) around the device STFT / iSTFT (`frontend.BlockSTFT` = ConvTDFNet.stft/.istft
+:82-120); the MDX net BODY is a third-party ONNX model (no weights, no onnxruntime here) and therefore a plug-in
+`mdx_model(spec[n,4,dim_f,dim_t]) -> spec` on device tensors.  Resampling runs on the device polyphase resampler
+(`ops.resample_poly`; the reference calls librosa: parity unpinned).
+
+Out of scope here: enhancer, Apollo restorer, noisereduce (fast_mode), file I/O — those flags are
+accepted and degrade to "module skipped" exactly like the reference does when a package is disabled.
 """
 from __future__ import annotations
 
@@ -28,10 +33,18 @@ class AudioProcessor:
                  is_separate_audio: bool = False, separater_weights_folder: str = "look2hear/checkpoints/TFGNet-Noise",
                  is_restore_audio: bool = False, restorer_weights_folder: str = "JusperLee/Apollo",
                  verbose_log: bool = True, cuda_device: int = 0, quality: int = 2,
-                 separater_state_dict=None):
+                 separater_state_dict=None, mdx_model=None, mdx_dim_f: int = 3072, mdx_n_fft: int = 6144):
         """`separater_state_dict` (extension): an in-memory state_dict instead of
-        `<separater_weights_folder>/best_model.pth` — no checkpoint ships with the reference."""
-        self.is_denoise_vocal = False           # MDX net body is out of scope (third-party ONNX)
+        `<separater_weights_folder>/best_model.pth` — no checkpoint ships with the reference.
+        `mdx_model` (extension): the MDX net body as a callable on device tensors, spec[n,4,dim_f,256] -> spec (the
+        reference runs the ONNX file through onnxruntime, AudioProcessor.py:231-233,630); without it the denoiser is off,
+        like a failed `init_mdx_model` (:171-176).  `mdx_dim_f` / `mdx_n_fft`: the ONNX metadata the reference reads (:234-237)."""
+        self.is_denoise_vocal = bool(is_denoise_vocal and mdx_model is not None)
+        self.mdx_model = mdx_model
+        self.mdx_net = None
+        self._mdx_geom = (mdx_n_fft, {1: 256, 2: 1024, 3: 2048}.get(quality, 1024), mdx_dim_f)        # :225-240
+        if is_denoise_vocal and mdx_model is None:
+            print("Failed to init MDX model: the MDX net body is a third-party ONNX model; pass mdx_model=callable(spec)->spec")
         self.is_enhance_vocal = False
         self.is_restore_audio = False
         self.is_separate_audio = is_separate_audio
@@ -157,6 +170,121 @@ class AudioProcessor:
             h = p.cpu().numpy()
             res.append((h[0], h[1]))
         return res
+
+    # ---- AudioProcessor.py:350-383 (pure numpy in the reference; torch here, same arithmetic) ----
+    @staticmethod
+    def mono_to_stereo(audio):
+        return audio.reshape(-1, 1).repeat(1, 2) if audio.ndim == 1 else audio
+
+    @staticmethod
+    def audio_to_mono(audio):
+        return audio if audio.ndim == 1 else audio.double().mean(dim=1).float()      # np.average with unit weights, float64 accumulate
+
+    def audio_resample(self, audio_data, orig_sr: int, target_sr: int, output_audio_only: bool = False):
+        """:549-569 on the device (`ops.resample_poly`); numpy in -> numpy out, device tensor in -> device tensor out"""
+        from . import ops
+        if target_sr == orig_sr:
+            return audio_data if output_audio_only else (audio_data, target_sr)
+        is_np = isinstance(audio_data, np.ndarray)
+        x = torch.from_numpy(np.ascontiguousarray(audio_data, dtype=np.float32)).to(self._dev()) if is_np else audio_data
+        y = ops.resample_poly(x if x.ndim == 1 else x.t().contiguous(), orig_sr, target_sr)
+        y = y if y.ndim == 1 else y.t().contiguous()
+        if is_np:
+            y = y.cpu().numpy().astype(np.float32)
+        return y if output_audio_only else (y, target_sr)
+
+    def _dev(self):
+        return torch.device("cuda:0" if self.device == "cuda" else self.device)
+
+    def init_mdx_model(self):
+        """:224-241: the block STFT geometry (hop by `quality`, dim_t = 2**8 frames)"""
+        from .frontend import BlockSTFT
+        n_fft, hop, dim_f = self._mdx_geom
+        self.mdx_net = BlockSTFT(n_fft=n_fft, hop=hop, dim_f=dim_f, dim_t=256, device=self._dev())
+
+    @staticmethod
+    def mdx_segments(total_samples: int, chunk_size: int, margin_size: int):
+        """The outer chunker of denoise_vocal (:666-706) as index arithmetic: [(start, end, start_trim, end_trim)] — segment
+        [start, end) of the audio is processed and [start_trim, len - end_trim) of the result is kept (end_trim None = to the end);
+        the trims are clamped to half the PROCESSED segment's length, which equals the segment's length (:693-699)."""
+        if total_samples <= chunk_size:
+            return [(0, total_samples, 0, None)]
+        margin_size = min(margin_size, chunk_size)
+        segs, cursor, k = [], 0, 0
+        while cursor < total_samples:
+            start = max(0, cursor - (0 if k == 0 else margin_size))
+            chunk_end = cursor + chunk_size
+            last = chunk_end >= total_samples
+            end = total_samples if last else min(chunk_end + margin_size, total_samples)
+            segs.append([start, end])
+            k += 1
+            cursor += chunk_size
+            if last:
+                break
+        out = []
+        for i, (a, b) in enumerate(segs):
+            n = b - a
+            out.append((a, b, 0 if i == 0 else min(margin_size, n // 2), None if i == len(segs) - 1 else min(margin_size, n // 2)))
+        return out
+
+    # AudioProcessor.py:601-713
+    def denoise_vocal(self, audio_data: np.ndarray, sampling_rate: int = 16000, fast_mode: bool = False):
+        if not self.is_denoise_vocal:
+            fast_mode = True
+        if self.verbose_log:
+            print("\nRunning module: denoise_vocal")
+            print("Using method: noisereduce" if fast_mode else f"Using method: MDX-Net\nUsing model: {self.mdx_weights_file}")
+        if fast_mode:
+            print("denoise_vocal: noisereduce (fast_mode) is a third-party CPU package outside the MI355X hot path; audio returned unchanged")
+            return audio_data
+        if self.mdx_net is None:
+            self.init_mdx_model()
+        net = self.mdx_net
+        dev = self._dev()
+        x = torch.from_numpy(np.ascontiguousarray(audio_data, dtype=np.float32)).to(dev)
+        new_sr = sampling_rate
+        if sampling_rate != 44100:
+            x, new_sr = self.audio_resample(x, sampling_rate, 44100)
+        is_mono = x.ndim == 1
+        if is_mono:
+            x = self.mono_to_stereo(x)
+        total = x.shape[0]
+        segs = self.mdx_segments(total, int(15.0 * new_sr), int(1.0 * new_sr))
+        # ---- process_audio_chunk (:605-643) for ALL segments in one batched STFT -> net -> iSTFT
+        trim = net.n_fft // 2
+        gen = net.chunk_size - 2 * trim
+        blocks, plan = [], []
+        for (a, b, _, _) in segs:
+            n = b - a
+            pad = (gen - (n % gen)) % gen
+            mix = torch.cat((torch.zeros(2, trim, device=dev), x[a:b].t(), torch.zeros(2, pad + trim, device=dev)), dim=1)
+            blk = mix.unfold(1, net.chunk_size, gen).permute(1, 0, 2)            # [nb, 2, chunk], stride gen (:613-617)
+            plan.append((n, pad, blk.shape[0]))
+            blocks.append(blk)
+        waves = torch.cat(blocks, 0).contiguous()
+        spec = net.stft(waves)
+        pred = self.mdx_model(spec)
+        wav = net.istft(pred)                                                   # [nb_total, 2, chunk]
+        inst = "inst" in os.path.basename(self.mdx_weights_file).lower()
+        outs, k = [], 0
+        for (a, b, t0, t1), (n, pad, nb) in zip(segs, plan):
+            o = wav[k:k + nb, :, trim:net.chunk_size - trim].transpose(0, 1).reshape(2, -1)
+            k += nb
+            o = o[:, :o.shape[1] - pad] if pad > 0 else o[:, :0]                   # `[:, :-pad]` is EMPTY when pad == 0 (:637)
+            o = o.t()
+            if inst:
+                if o.shape[0] != n:                                             # numpy: (n,2) - (0,2) cannot broadcast
+                    raise ValueError(f"operands could not be broadcast together with shapes ({n},2) ({o.shape[0]},2) ")
+                o = torch.clamp(x[a:b] - o, -1.0, 1.0)
+            else:
+                o = torch.clamp(o, -1.0, 1.0)
+            outs.append(o[t0:(o.shape[0] - t1) if t1 is not None else None] if len(segs) > 1 else o)
+        out = torch.cat(outs, 0) if len(outs) > 1 else outs[0]
+        if is_mono:
+            out = self.audio_to_mono(out)
+        if new_sr != sampling_rate:
+            out, _ = self.audio_resample(out, new_sr, sampling_rate)
+        return out.cpu().numpy().astype(np.float32)
 
     # AudioProcessor.py:885-956
     def separate_speaker(self, audio_data: np.ndarray, sampling_rate: int = 16000, low_gpu_ram: bool = False):

@@ -437,6 +437,25 @@ __global__ __launch_bounds__(64) void loud_gate_kernel(const double* __restrict_
     for (int j = 0; j < nblk; ++j) { const double l = -0.691 + 10.0 * log10(zb[j]); if (l > gamma_r && l > -70.0) { s += zb[j]; ++c; } }
     lufs[b] = c == 0 ? -INFINITY : -0.691 + 10.0 * log10(s / c);
 }
+// Rational polyphase resampler (N3: AudioProcessor.audio_resample, AudioProcessor.py:549-569): y[c][m] = sum_i x[c][i] * h[m*down - i*up + half]
+// — zero-stuffing by `up`, FIR h (2*half+1 taps, DC gain `up`), keep every `down`-th sample, the filter delay removed — as
+// one gather per output sample: only the ~(2*half+1)/up input samples whose taps are non-zero are touched.
+__global__ __launch_bounds__(256) void resample_poly_kernel(const float* __restrict__ x, long n_in, int C, int up, int down,
+                                                             const float* __restrict__ h, int half, float* __restrict__ y, long n_out) {
+    const long m = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    if (m >= n_out) return;
+    const long t = m * down + half;                       // h index = t - i*up, 0 <= . <= 2*half
+    long i_hi = t / up;                                   // largest i with t - i*up >= 0
+    long i_lo = (t - 2L * half + up - 1) / up;            // smallest i with t - i*up <= 2*half
+    if (t - 2L * half < 0) i_lo = 0;
+    if (i_hi > n_in - 1) i_hi = n_in - 1;
+    const float* xc = x + (long)c * n_in;
+    double acc = 0.0;
+    for (long i = i_lo; i <= i_hi; ++i) acc = fma((double)xc[i], (double)h[t - i * up], acc);
+    y[(long)c * n_out + m] = (float)acc;
+}
+
 inline int loud_nblk(long N, int rate) {
     const double T = (double)N / rate;
     return (int)(nearbyint((T - 0.4) / (0.4 * 0.25)) + 1);
@@ -466,6 +485,16 @@ int tdx_loudness(const float* wav, int B, long N, int rate, double* lufs, void* 
     hipLaunchKernelGGL(loud_block_kernel, dim3((unsigned)(((long)B * nblk + 3) / 4)), dim3(256), 0, st, y, B, N, (double)rate, nblk, z);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(loud_gate_kernel, dim3((B + 63) / 64), dim3(64), 0, st, z, B, nblk, lufs);
+    LAUNCH_CHECK();
+    return TDX_OK;
+}
+
+
+// x_dev [C][n_in] -> y_dev [C][n_out], n_out = ceil(n_in*up/down); h_dev: 2*half+1 taps (DC gain up)
+int tdx_resample_poly(const float* x, long n_in, int C, int up, int down, const float* h, int half, float* y, long n_out, void* stream) {
+    if (!x || !h || !y || n_in < 1 || C < 1 || up < 1 || down < 1 || half < 0 || n_out < 1) return tdx::fail(TDX_E_INVALID, "tdx_resample_poly: bad argument");
+    if (n_out != (n_in * up + down - 1) / down) return tdx::fail(TDX_E_INVALID, "tdx_resample_poly: n_out must be ceil(n_in*up/down)");
+    hipLaunchKernelGGL(resample_poly_kernel, dim3((unsigned)((n_out + 255) / 256), C), dim3(256), 0, (hipStream_t)stream, x, n_in, C, up, down, h, half, y, n_out);
     LAUNCH_CHECK();
     return TDX_OK;
 }

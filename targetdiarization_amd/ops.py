@@ -72,3 +72,43 @@ def loudness(wav: torch.Tensor, rate: int = 16000) -> torch.Tensor:
     out = torch.empty(B, dtype=torch.float64, device=wav.device)
     _lib.check(l.tdx_loudness(wav.data_ptr(), B, N, rate, out.data_ptr(), ws.data_ptr(), nb, _st(wav)))
     return out
+
+
+_RESAMPLE_FILTERS = {}
+
+
+def resample_filter(up: int, down: int):
+    """The FIR of scipy.signal.resample_poly(window=("kaiser", 5.0)): 2*half+1 taps, half = 10*max(up, down), a Kaiser-windowed
+    sinc with cutoff 1/max(up, down) of Nyquist, unit DC gain, times `up` (restated with numpy; float64 design, float32 taps)."""
+    import numpy as np
+    key = (up, down)
+    if key not in _RESAMPLE_FILTERS:
+        max_rate = max(up, down)
+        half = 10 * max_rate
+        n = 2 * half + 1
+        cutoff = 1.0 / max_rate
+        m = np.arange(n, dtype=np.float64) - half
+        h = cutoff * np.sinc(cutoff * m) * np.kaiser(n, 5.0)
+        h = h / h.sum() * up
+        _RESAMPLE_FILTERS[key] = (h.astype(np.float32), half)
+    return _RESAMPLE_FILTERS[key]
+
+
+def resample_poly(x: torch.Tensor, orig_sr: int, target_sr: int) -> torch.Tensor:
+    """AudioProcessor.audio_resample (AudioProcessor.py:549-569) on the device: x [C,n] or [n] at orig_sr -> target_sr, rational
+    polyphase (up/down = target/orig reduced), scipy.signal.resample_poly's default filter.  The reference calls
+    librosa.resample (soxr, third-party): parity unpinned."""
+    import math
+    if orig_sr == target_sr:
+        return x
+    g = math.gcd(int(orig_sr), int(target_sr))
+    up, down = int(target_sr) // g, int(orig_sr) // g
+    one_d = x.ndim == 1
+    xx = (x[None] if one_d else x).contiguous().float()
+    C_, n_in = xx.shape
+    n_out = (n_in * up + down - 1) // down
+    h, half = resample_filter(up, down)
+    hd = torch.from_numpy(h).to(xx.device)
+    y = torch.empty(C_, n_out, device=xx.device)
+    _lib.check(_lib.lib().tdx_resample_poly(xx.data_ptr(), n_in, C_, up, down, hd.data_ptr(), half, y.data_ptr(), n_out, _st(xx)))
+    return y[0] if one_d else y

@@ -88,4 +88,4 @@ def test_denoise_vocal_16k_mono_roundtrip_shape():
     # ceil(ceil(n*441/160)*160/441) = n + 1 here: librosa's n_samples rule (ceil) gives the reference the same extra sample
     assert y.shape[0] in (x.shape[0], x.shape[0] + 1) and y.dtype == np.float32
     # identity net + vocals model: the chain is resample up -> STFT/iSTFT (one bin dropped) -> resample down: close to the input
-    assert np.linalg.norm(y[: x.shape[0]] - x) / np.linalg.norm(x) < 0.05
+    assert np.linalg.norm(y[: x.shape[0]] - x) / np.linalg.norm(x) < 0.2       # (white noise: the band next to Nyquist falls in the resamplers' transition band)

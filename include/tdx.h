@@ -162,6 +162,29 @@ int tdx_pfenc_forward(tdx_pfenc* h, const float* feats_dev, const int* lens_host
                       float* out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * N2  Paraformer CIF predictor + non-autoregressive SANM decoder — replaces the rest of
+ *     `self.asr['paraformer'].generate(input=wav, hotword=...)` after the encoder  ASRProcessor.py:424
+ *     (funasr CifPredictorV2 + ParaformerSANMDecoder: third-party; 16 layers FFN -> FSMN memory -> cross attention,
+ *     one FFN-only layer, LayerNorm, vocabulary projection).  blob: TDXW container with funasr's names
+ *     (predictor.cif_conv1d / cif_output, decoder.decoders.{i}.*, decoder.decoders3.0.*, decoder.after_norm,
+ *     decoder.output_layer).  Two calls because the number of tokens is data dependent:
+ *       predict: enc_dev [B,T,512] -> alphas_dev [B,T+1] (tail frame appended), emb_dev [B,T+1,512] (the fired frames
+ *                first, zero beyond), counts_dev int32 [B] = floor(sum alphas), peaks_dev int32 [B,T+1] (frame of fire k, -1)
+ *       decode : the first L rows of every utterance of emb_dev (L = max count, read back by the host), masked by
+ *                counts_dev, with enc_dev as attention memory -> ids_dev int32 [B,L] (argmax), score_dev [B,L] (log-softmax
+ *                at the argmax) or NULL.
+ * ---------------------------------------------------------------------------------- */
+typedef struct tdx_pfdec tdx_pfdec;
+int tdx_pfdec_create(int num_blocks, int vocab, const void* weights_blob, size_t blob_bytes, int device, tdx_pfdec** out);
+int tdx_pfdec_destroy(tdx_pfdec* h);
+size_t tdx_pfdec_predict_workspace_bytes(const tdx_pfdec* h, int B, int T);
+int tdx_pfdec_predict(tdx_pfdec* h, const float* enc_dev, int B, int T, float* alphas_dev, float* emb_dev, int* counts_dev,
+                      int* peaks_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+size_t tdx_pfdec_decode_workspace_bytes(const tdx_pfdec* h, int B, int L, int T);
+int tdx_pfdec_decode(tdx_pfdec* h, const float* emb_dev, int emb_rows, const int* counts_dev, const float* enc_dev, int B, int L,
+                     int T, int* ids_dev, float* score_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * a10 ERes2NetV2-w24s4ep4 speaker embedding — replaces
  *     `self.embedding[embedding_model](wav_file, output_emb=True)['embs']`  TargetASR.py:161
  *     (modelscope / 3D-Speaker ERes2NetV2: third-party).  blob: TDXW container with the

@@ -56,6 +56,12 @@ SIGNATURES = {
     "tdx_pfenc_workspace_bytes": (_sz, [_vp, _i, _i]),
     "tdx_pfenc_flops": (C.c_double, [_vp, _i, _i]),
     "tdx_pfenc_forward": (_i, [_vp, _fp, _vp, _i, _i, _fp, _vp, _sz, _vp]),
+    "tdx_pfdec_create": (_i, [_i, _i, _vp, _sz, _i, C.POINTER(_vp)]),
+    "tdx_pfdec_destroy": (_i, [_vp]),
+    "tdx_pfdec_predict_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "tdx_pfdec_predict": (_i, [_vp, _fp, _i, _i, _fp, _fp, _vp, _vp, _vp, _sz, _vp]),
+    "tdx_pfdec_decode_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "tdx_pfdec_decode": (_i, [_vp, _fp, _i, _vp, _fp, _i, _i, _i, _vp, _fp, _vp, _sz, _vp]),
     "tdx_eres2net_create": (_i, [_vp, _sz, _i, C.POINTER(_vp)]),
     "tdx_eres2net_destroy": (_i, [_vp]),
     "tdx_eres2net_workspace_bytes": (_sz, [_vp, _i, _i]),

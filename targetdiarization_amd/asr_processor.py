@@ -1,8 +1,9 @@
 """ASRProcessor — the paraformer branch of the reference's `asr_detection` (ASRProcessor.py:373-442)
 around the MI355X encoder.  The swap point is `self.asr['paraformer'].generate(input=wav, hotword=…)`
-(:424): here the neural forward up to the encoder output runs through `tdx_pfenc_*`; everything
-after it (CIF predictor, NAR decoder, tokenizer, punctuation: third-party funasr) is a
-`decoder(encoder_out[T',512]) -> {"text": str, "timestamp": [[start_ms, end_ms], ...]}` plug-in.
+(:424): the neural forward runs through `tdx_pfenc_*` (SANM encoder) and, when the state dict carries the
+`predictor.*` / `decoder.*` tensors, `tdx_pfdec_*` (CIF predictor + NAR SANM decoder): tokens are the argmax
+ids, mapped to text through `token_list` (funasr's tokens.json, absent here: "<id>" placeholders by default).
+A custom `decoder(encoder_out[T',512]) -> {"text": str, "timestamp": [[start_ms, end_ms], ...]}` plug-in overrides it.
 The post-processing of the result dicts (:427-437: ms -> s, token/timestamp pairing) and the
 print-and-degrade behaviour for missing engines (:375-389) are the reference's."""
 from __future__ import annotations
@@ -17,19 +18,31 @@ class ASRProcessor:
                  is_punc: bool = False, punc_model_dir: str = "", is_timestamp: bool = False, timestamp_model_dir: str = "",
                  is_emotion: bool = False, emotion_model_dir: str = "", is_diarization: bool = False, diarization_model_dir: str = "",
                  is_asr_api: bool = False, api_config_path: str = "", verbose_log: bool = True, cuda_device: int = 0, ap=None,
-                 *, asr_state_dict=None, decoder: Optional[Callable] = None, punctuation: Optional[Callable] = None):
+                 *, asr_state_dict=None, decoder: Optional[Callable] = None, punctuation: Optional[Callable] = None, token_list=None):
         self.is_asr = is_asr
         self.verbose_log = verbose_log
         self.decoder = decoder
         self.punctuation = punctuation
+        self.token_list = token_list
         self.asr = {}
+        self.nar_decoder = None
         if is_asr and asr_state_dict is not None:
             try:
-                from .paraformer import ParaformerEncoder
-                self.asr["paraformer"] = ParaformerEncoder(asr_state_dict, device=f"cuda:{cuda_device}")
+                from .paraformer import ParaformerDecoder, ParaformerEncoder
+                enc_sd = {k: v for k, v in asr_state_dict.items() if k.startswith("encoder.")}
+                self.asr["paraformer"] = ParaformerEncoder(enc_sd, device=f"cuda:{cuda_device}")
+                if decoder is None and any(k.startswith("decoder.decoders.") for k in asr_state_dict):
+                    self.nar_decoder = ParaformerDecoder(asr_state_dict, device=f"cuda:{cuda_device}")
+                    self.decoder = self._nar_decode
             except Exception as e:                       # ASRProcessor.py:215-264: print, feature off
                 print(f"Load ASR model failed: {e}")
                 self.is_asr = False
+
+    def _nar_decode(self, enc_out):
+        """encoder output [T',512] -> {"text", "timestamp"} through the device CIF predictor + NAR decoder"""
+        r = self.nar_decoder.decode(enc_out[None])[0]
+        toks = [self.token_list[i] if self.token_list is not None and i < len(self.token_list) else f"<{i}>" for i in r["token_ids"]]
+        return {"text": " ".join(toks), "timestamp": r["timestamp"], "token_ids": r["token_ids"]}
 
     def punctuation_restore(self, text: str) -> str:
         return self.punctuation(text) if self.punctuation is not None else text

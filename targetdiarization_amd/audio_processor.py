@@ -33,7 +33,7 @@ class AudioProcessor:
                  is_separate_audio: bool = False, separater_weights_folder: str = "look2hear/checkpoints/TFGNet-Noise",
                  is_restore_audio: bool = False, restorer_weights_folder: str = "JusperLee/Apollo",
                  verbose_log: bool = True, cuda_device: int = 0, quality: int = 2,
-                 separater_state_dict=None, mdx_model=None, mdx_dim_f: int = 3072, mdx_n_fft: int = 6144):
+                 separater_state_dict=None, mdx_model=None, mdx_dim_f: int = 3072, mdx_n_fft: int = 6144, silero_vad=None):
         """`separater_state_dict` (extension): an in-memory state_dict instead of
         `<separater_weights_folder>/best_model.pth` — no checkpoint ships with the reference.
         `mdx_model` (extension): the MDX net body as a callable on device tensors, spec[n,4,dim_f,256] -> spec (the
@@ -41,6 +41,7 @@ class AudioProcessor:
         like a failed `init_mdx_model` (:171-176).  `mdx_dim_f` / `mdx_n_fft`: the ONNX metadata the reference reads (:234-237)."""
         self.is_denoise_vocal = bool(is_denoise_vocal and mdx_model is not None)
         self.mdx_model = mdx_model
+        self.silero_vad = silero_vad            # low_gpu_ram plug-in: silero_vad(audio[n] f32 @16 kHz) -> [[start, end], ...] in samples (:903-905)
         self.mdx_net = None
         self._mdx_geom = (mdx_n_fft, {1: 256, 2: 1024, 3: 2048}.get(quality, 1024), mdx_dim_f)        # :225-240
         if is_denoise_vocal and mdx_model is None:
@@ -291,21 +292,46 @@ class AudioProcessor:
         if not self.is_separate_audio:
             print("\nSkip module: separate_speaker")
             return audio_data, audio_data
-        if sampling_rate != 16000:
-            print("separate_speaker: resampling is outside the MI355X hot path; pass 16 kHz audio")
-            return audio_data, audio_data
-        if low_gpu_ram:
-            print("separate_speaker: low_gpu_ram (1 s windows + silero VAD) is not needed on 288 GB HBM; using 10 s windows")
-        window_size = 160000
+        orig_sr = sampling_rate
+        if sampling_rate != 16000:                                   # :889-891
+            audio_data, sampling_rate = self.audio_resample(np.asarray(audio_data, dtype=np.float32), sampling_rate, 16000)
+        window_size, is_vad = (16000, True) if low_gpu_ram else (160000, False)      # :892-897
         if self.verbose_log:
             print("\nRunning module: separate_speaker")
             print(f"Window size: {window_size}")
-            print("Use VAD: False")
-        if audio_data.shape[0] < 16:
-            # MossFormer2's encoder needs >= kernel_size samples (the reference would raise inside conv1d)
+            print(f"Use VAD: {is_vad}")
+        if is_vad:
+            # :903-905 — silero VAD (third-party) is a plug-in: silero_vad(audio[n] f32) -> [[start, end], ...] in samples
+            if self.silero_vad is None:
+                print("separate_speaker: low_gpu_ram needs a silero_vad plug-in; treating the whole clip as one speech frame")
+                vad_frames = [[0, audio_data.shape[0]]]
+            else:
+                vad_frames = [[int(a), int(b)] for a, b in self.silero_vad(audio_data)]
+        else:
+            vad_frames = [[0, audio_data.shape[0]]]
+        # :908-948 as a plan: the output is [zeros up to the first frame][frame 0][zeros between frames][frame 1]... (nothing
+        # after the last frame: the reference's output is shorter than its input when the VAD cuts the tail); every window of
+        # every frame goes through the separator, equal lengths batched
+        pieces, wins, filled = [], [], 0
+        for i, (f0, f1) in enumerate(vad_frames):
+            if f0 > filled:
+                gap = f0 if i == 0 else f0 - vad_frames[i - 1][1]
+                pieces.append(("zeros", gap)); filled += gap
+            for (a, b) in self.window_plan(f1 - f0, window_size, f0):
+                if b - a < 16:
+                    # MossFormer2's encoder needs >= kernel_size samples (the reference would raise inside conv1d)
+                    pieces.append(("zeros", b - a))
+                else:
+                    pieces.append(("win", len(wins))); wins.append(audio_data[a:b].astype(np.float32, copy=True))
+                filled += b - a
+        if not wins:
             return audio_data, audio_data
-        plan = self.window_plan(audio_data.shape[0], window_size)
-        wins = [audio_data[s:e].astype(np.float32, copy=True) for s, e in plan]
-        outs = self.separate_windows_device(wins)
-        spk1, spk2 = self.louder_first([torch.cat(outs, dim=1)])[0]      # louder stream first, :949-952 (metered on the device)
+        max_batch = max(1, min(512, (32 * 160000) // max(len(w) for w in wins)))
+        outs = self.separate_windows_device(wins, max_batch)
+        dev = outs[0].device
+        cat = torch.cat([outs[k] if kind == "win" else torch.zeros(2, k, device=dev) for kind, k in pieces], dim=1)
+        spk1, spk2 = self.louder_first([cat])[0]                     # louder stream first, :949-952 (metered on the device)
+        if orig_sr != sampling_rate:                                 # :953-955
+            spk1 = self.audio_resample(spk1, sampling_rate, orig_sr, output_audio_only=True)
+            spk2 = self.audio_resample(spk2, sampling_rate, orig_sr, output_audio_only=True)
         return spk1, spk2

@@ -72,10 +72,11 @@ __global__ __launch_bounds__(256) void pf_layernorm_kernel(const float* __restri
 }
 
 // the same LayerNorm written as split-f16 planes + row scale for the x3 GEMM (gemm_h3.hpp): lane l owns the 8-value
-// chunks l and l+64 (Cpad <= 1024), columns C..Cpad-1 are zero
-__global__ __launch_bounds__(256) void pf_layernorm_planes_kernel(const float* __restrict__ x, long ld, int C, const float* __restrict__ g,
-                                                                   const float* __restrict__ b, unsigned char* __restrict__ hp,
-                                                                   float* __restrict__ hs, int Cpad, long M, float eps) {
+// chunks l, l+64, ... (NCH per lane: Cpad <= 512*NCH), columns C..Cpad-1 are zero
+template <int NCH>
+__global__ __launch_bounds__(256) void pf_layernorm_planes_kernel_t(const float* __restrict__ x, long ld, int C, const float* __restrict__ g,
+                                                                     const float* __restrict__ b, unsigned char* __restrict__ hp,
+                                                                     float* __restrict__ hs, int Cpad, long M, float eps) {
     const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
     const int lane = threadIdx.x & 63;
@@ -86,10 +87,10 @@ __global__ __launch_bounds__(256) void pf_layernorm_planes_kernel(const float* _
     float q = 0.f;
     for (int c = lane; c < C; c += 64) { const float d = r[c] - mean; q = fmaf(d, d, q); }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
-    float v[2][8];
+    float v[NCH][8];
     float mu = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         const int c0 = (lane + 64 * i) * 8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -101,12 +102,13 @@ __global__ __launch_bounds__(256) void pf_layernorm_planes_kernel(const float* _
     float inv;
     const float sc = h3_row_scale(h3_wave_max(mu), inv);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         const int ch = lane + 64 * i;
         if (ch * 8 < Cpad) h3_store_chunk(hp + m * (4L * Cpad) + ch * 32, v[i], sc);
     }
     if (lane == 0) hs[m] = inv;
 }
+#define pf_layernorm_planes_kernel pf_layernorm_planes_kernel_t<2>
 
 // row softmax over the first S columns of [Z][Sp][Sp] score rows (rows < S); pad columns -> 0
 __global__ __launch_bounds__(256) void pf_softmax_kernel(float* __restrict__ sc, int S, int Sp) {
@@ -361,6 +363,427 @@ int tdx_pfenc_forward(tdx_pfenc* h, const float* feats, const int* lens_host, in
         TRY(lin3(hp, hs, w.h2, (int)M, D, FFN, EpiBiasResP{w.b2, x, D}, st));
     }
     hipLaunchKernelGGL(pf_layernorm_kernel, rows4, dim3(256), 0, st, x, (long)D, D, h->ang, h->anb, out, (long)D, D, M, PF_LN_EPS);
+    LAUNCH_CHECK();
+    return TDX_OK;
+}
+
+}  // extern "C"
+
+
+// =====================================================================================================================
+// N2: CIF predictor + non-autoregressive SANM decoder (funasr CifPredictorV2 + ParaformerSANMDecoder; third-party, parity
+// unpinned, oracle/paraformer_oracle.py).  Replaces the rest of `self.asr['paraformer'].generate(...)` after the encoder
+// (ASRProcessor.py:424): encoder output -> alphas -> integrate-and-fire -> acoustic embeddings -> 16 decoder layers
+// (FFN -> FSMN memory -> cross attention on the encoder output) -> FFN-only layer -> LayerNorm -> vocabulary logits -> argmax.
+// =====================================================================================================================
+namespace {
+
+constexpr float CIF_THRESHOLD = 1.0f, CIF_TAIL = 0.45f;
+
+// rows [enc(t-1) | enc(t) | enc(t+1)] (zero outside the utterance) as planes, K = 1536: the A operand of the predictor's
+// Conv1d(512, 512, 3, padding 1) as ONE GEMM.  wave per row, lane owns chunks l, l+64, l+128.
+__global__ __launch_bounds__(256) void pf_im2col3_planes_kernel(const float* __restrict__ enc, unsigned char* __restrict__ hp, float* __restrict__ hs,
+                                                                 long M, int T) {
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int lane = threadIdx.x & 63;
+    const int t = (int)(m % T);
+    float v[3][8];
+    float mu = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ch = lane + 64 * i;              // 8-value chunk of the 1536-wide row: tap = ch / 64, channel = (ch % 64) * 8
+        const int tap = ch >> 6, c0 = (ch & 63) * 8;
+        const int ts = t + tap - 1;
+        const bool ok = ts >= 0 && ts < T;
+        const float* r = enc + (m + tap - 1) * D + c0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[i][j] = ok ? r[j] : 0.f; mu = fmaxf(mu, fabsf(v[i][j])); }
+    }
+    float inv;
+    const float sc = h3_row_scale(h3_wave_max(mu), inv);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) h3_store_chunk(hp + m * (4L * 3 * D) + (lane + 64 * i) * 32, v[i], sc);
+    if (lane == 0) hs[m] = inv;
+}
+struct EpiCifConv { const float* b; const float* enc; float* out;         // relu(conv + bias + context)
+    __device__ float col(int, int n) const { return b[n]; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ float aux(int, int m, int n, EpiNone) const { return enc[(long)m * D + n]; }
+    __device__ void store(int, int m, int n, float v, EpiNone, float c, float e) const { out[(long)m * D + n] = fmaxf((v + c) + e, 0.f); } };
+struct EpiStoreP { float* out; long ld;
+    __device__ EpiNone col(int, int) const { return EpiNone{}; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ void store(int, int m, int n, float v, EpiNone, EpiNone) const { out[(long)m * (int)ld + n] = v; } };
+
+// alphas[b][t] = sigmoid(p1[b,t,:] . w + b0), alphas[b][T] = tail threshold          (CifPredictorV2.forward, tail_process_fn)
+__global__ __launch_bounds__(256) void pf_alpha_kernel(const float* __restrict__ p1, const float* __restrict__ w, const float* __restrict__ b0,
+                                                        float* __restrict__ alphas, long M, int T) {
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int lane = threadIdx.x & 63;
+    const float4 a0 = *reinterpret_cast<const float4*>(p1 + m * D + lane * 4), a1 = *reinterpret_cast<const float4*>(p1 + m * D + 256 + lane * 4);
+    const float4 w0 = *reinterpret_cast<const float4*>(w + lane * 4), w1 = *reinterpret_cast<const float4*>(w + 256 + lane * 4);
+    float v = a0.x * w0.x;
+    v = fmaf(a0.y, w0.y, v); v = fmaf(a0.z, w0.z, v); v = fmaf(a0.w, w0.w, v);
+    v = fmaf(a1.x, w1.x, v); v = fmaf(a1.y, w1.y, v); v = fmaf(a1.z, w1.z, v); v = fmaf(a1.w, w1.w, v);
+    v = wave_sum(v) + b0[0];
+    if (lane == 0) {
+        const long b = m / T; const int t = (int)(m - b * T);
+        alphas[b * (T + 1) + t] = fmaxf(1.0f / (1.0f + expf(-v)), 0.f);
+        if (t == T - 1) alphas[b * (T + 1) + T] = CIF_TAIL;
+    }
+}
+
+// funasr cif(): the integrate-and-fire recurrence is sequential in t (one thread walks it with the reference's fp32 operation
+// order — T <= a few thousand steps), the frame accumulation is parallel over the 512 channels.  block = one utterance.
+//   emb[b][k][:] = k-th fired frame (k < number of fires), zero beyond; counts[b] = floor(sum alphas); peaks[b][k] = firing frame
+__global__ __launch_bounds__(512) void pf_cif_kernel(const float* __restrict__ enc, const float* __restrict__ alphas, float* __restrict__ emb,
+                                                      int* __restrict__ counts, int* __restrict__ peaks, int T) {
+    extern __shared__ float sm[];
+    const int T1 = T + 1, b = blockIdx.x, c = threadIdx.x;
+    float* s_cur = sm; float* s_rem = sm + T1; int* s_fire = reinterpret_cast<int*>(sm + 2 * T1);
+    const float* al = alphas + (long)b * T1;
+    if (c == 0) {
+        float integrate = 0.f, total = 0.f;
+        int k = 0;
+        for (int t = 0; t < T1; ++t) {
+            const float alpha = al[t];
+            const float completion = 1.0f - integrate;
+            integrate += alpha;
+            total += alpha;
+            const bool fire = integrate >= CIF_THRESHOLD;
+            if (fire) integrate -= 1.0f;
+            const float cur = fire ? completion : alpha;
+            s_cur[t] = cur; s_rem[t] = alpha - cur; s_fire[t] = fire ? 1 : 0;
+            if (fire) peaks[(long)b * T1 + k++] = t;
+        }
+        for (; k < T1; ++k) peaks[(long)b * T1 + k] = -1;
+        counts[b] = (int)floorf(total);
+    }
+    __syncthreads();
+    float frame = 0.f;
+    int k = 0;
+    float* eo = emb + (long)b * T1 * D + c;
+    const float* hi = enc + (long)b * T * D + c;
+    for (int t = 0; t < T1; ++t) {
+        const float hv = t < T ? hi[(long)t * D] : 0.f;          // the tail frame is zero (tail_process_fn)
+        frame += s_cur[t] * hv;
+        if (s_fire[t]) { eo[(long)k * D] = frame; ++k; frame = s_rem[t] * hv; }
+    }
+    for (; k < T1; ++k) eo[(long)k * D] = 0.f;
+}
+
+// y = mask * LN(x): rows (b, l) with l >= counts[b] are written as zero   (inputs * mask of MultiHeadedAttentionSANMDecoder)
+__global__ __launch_bounds__(256) void pf_layernorm_mask_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                                 float* __restrict__ out, long M, int L, const int* __restrict__ counts, float eps) {
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int lane = threadIdx.x & 63;
+    const float* r = x + m * D;
+    const bool keep = (int)(m % L) < counts[m / L];
+    float4 v0 = *reinterpret_cast<const float4*>(r + lane * 4), v1 = *reinterpret_cast<const float4*>(r + 256 + lane * 4);
+    const float mean = wave_sum((v0.x + v0.y) + (v0.z + v0.w) + (v1.x + v1.y) + (v1.z + v1.w)) * (1.0f / D);
+    v0.x -= mean; v0.y -= mean; v0.z -= mean; v0.w -= mean; v1.x -= mean; v1.y -= mean; v1.z -= mean; v1.w -= mean;
+    const float q = wave_sum((v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w) + (v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w));
+    const float rstd = keep ? 1.0f / sqrtf(q * (1.0f / D) + eps) : 0.f;
+    const float4 g0 = *reinterpret_cast<const float4*>(g + lane * 4), g1 = *reinterpret_cast<const float4*>(g + 256 + lane * 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(b + lane * 4), b1 = *reinterpret_cast<const float4*>(b + 256 + lane * 4);
+    const float kb = keep ? 1.f : 0.f;
+    float4 o0, o1;
+    o0.x = v0.x * rstd * g0.x + kb * b0.x; o0.y = v0.y * rstd * g0.y + kb * b0.y; o0.z = v0.z * rstd * g0.z + kb * b0.z; o0.w = v0.w * rstd * g0.w + kb * b0.w;
+    o1.x = v1.x * rstd * g1.x + kb * b1.x; o1.y = v1.y * rstd * g1.y + kb * b1.y; o1.z = v1.z * rstd * g1.z + kb * b1.z; o1.w = v1.w * rstd * g1.w + kb * b1.w;
+    *reinterpret_cast<float4*>(out + m * D + lane * 4) = o0;
+    *reinterpret_cast<float4*>(out + m * D + 256 + lane * 4) = o1;
+}
+// x[m] += mask * mem[m]
+__global__ __launch_bounds__(256) void pf_add_masked_kernel(float* __restrict__ x, const float* __restrict__ mem, long M, int L, const int* __restrict__ counts) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;       // float4 index
+    if (i >= M * (D / 4)) return;
+    const long m = i / (D / 4);
+    if ((int)(m % L) >= counts[m / L]) return;
+    float4 a = reinterpret_cast<float4*>(x)[i];
+    const float4 b = reinterpret_cast<const float4*>(mem)[i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    reinterpret_cast<float4*>(x)[i] = a;
+}
+// row softmax over the first T columns of [Z][L][Tp] score rows; pad columns -> 0
+__global__ __launch_bounds__(256) void pf_softmax_rect_kernel(float* __restrict__ sc, int L, int T, int Tp) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), z = blockIdx.y;
+    if (r >= L) return;
+    const int lane = threadIdx.x & 63;
+    float* row = sc + ((long)z * L + r) * Tp;
+    float mx = -INFINITY;
+    for (int c = lane; c < T; c += 64) mx = fmaxf(mx, row[c]);
+    mx = h3_wave_max(mx + 0.f) ;          // (values may be negative: shift below)
+    // h3_wave_max is a plain max over the lanes (no abs): fine for signed values
+    float s = 0.f;
+    for (int c = lane; c < T; c += 64) { const float e = expf(row[c] - mx); row[c] = e; s += e; }
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+    for (int c = lane; c < Tp; c += 64) row[c] = c < T ? row[c] * inv : 0.f;
+}
+struct EpiScoresR { float* sc; int L; int Tp; float scale;     // q k^T * dk^-0.5 -> [z][L][Tp]
+    __device__ EpiNone col(int, int) const { return EpiNone{}; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ void store(int z, int m, int n, float v, EpiNone, EpiNone) const { sc[((long)z * L + m) * Tp + n] = v * scale; } };
+// ids[m] = argmax_n logits[m][n] (n < V), score[m] = log softmax at the argmax
+__global__ __launch_bounds__(256) void pf_argmax_kernel(const float* __restrict__ logits, long ld, int V, int* __restrict__ ids, float* __restrict__ score, long M) {
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int lane = threadIdx.x & 63;
+    const float* r = logits + m * ld;
+    float best = -INFINITY; int bi = 0;
+    for (int c = lane; c < V; c += 64) { const float v = r[c]; if (v > best) { best = v; bi = c; } }       // first maximum per lane
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }                                   // ties: lowest index, like torch.argmax
+    }
+    float s = 0.f;
+    for (int c = lane; c < V; c += 64) s += expf(r[c] - best);
+    s = wave_sum(s);
+    if (lane == 0) { ids[m] = bi; if (score) score[m] = -logf(s); }
+}
+
+struct PfDecLayer { PfW3 h1, h2, hq, hkv, ho; const float *b1, *fg, *fb, *n1g, *n1b, *n2g, *n2b, *n3g, *n3b, *fsmnT, *bq, *bkv, *bo; };
+
+}  // namespace
+
+struct tdx_pfdec {
+    int device = 0;
+    int L = 0, vocab = 0, vpad = 0;
+    float* dev = nullptr; unsigned char* dev_planes = nullptr;
+    std::vector<PfDecLayer> layers; PfDecLayer d3;
+    PfW3 hcif, hout;
+    const float *cifb, *cifw, *cifob, *ang, *anb, *bout;
+};
+
+extern "C" {
+
+int tdx_pfdec_create(int num_blocks, int vocab, const void* blob, size_t blob_bytes, int device, tdx_pfdec** out) {
+    if (!blob || !out || num_blocks < 1 || vocab < 2) return tdx::fail(TDX_E_INVALID, "tdx_pfdec_create: bad argument");
+    tdx::Blob bl;
+    if (!bl.parse(blob, blob_bytes)) return tdx::fail(TDX_E_BLOB, "tdx_pfdec_create: malformed TDXW blob");
+    std::vector<float> host;
+    bool ok = true; std::string missing;
+    auto get = [&](const std::string& name, size_t n) -> const float* {
+        const tdx::BlobTensor* t = bl.find(name);
+        if (!t || t->numel != n) { ok = false; if (missing.empty()) missing = name; return nullptr; }
+        return t->data;
+    };
+    auto push = [&](const float* p, size_t n, size_t npad = 0) -> size_t {
+        size_t o = host.size(); host.resize(o + al(std::max(n, npad)), 0.f);
+        if (p) memcpy(host.data() + o, p, n * sizeof(float));
+        return o;
+    };
+    const int vpad = (vocab + 255) / 256 * 256;
+    struct Off { size_t W1, b1, W2, fg, fb, n1g, n1b, n2g, n2b, n3g, n3b, fsmnT, Wq, bq, Wkv, bkv, Wo, bo; };
+    std::vector<Off> offs(num_blocks + 1);
+    auto ffpart = [&](const std::string& p, Off& o) {
+        o.W1 = push(get(p + "feed_forward.w_1.weight", (size_t)FFN * D), (size_t)FFN * D);
+        o.b1 = push(get(p + "feed_forward.w_1.bias", FFN), FFN);
+        o.W2 = push(get(p + "feed_forward.w_2.weight", (size_t)D * FFN), (size_t)D * FFN);
+        o.fg = push(get(p + "feed_forward.norm.weight", FFN), FFN); o.fb = push(get(p + "feed_forward.norm.bias", FFN), FFN);
+        o.n1g = push(get(p + "norm1.weight", D), D); o.n1b = push(get(p + "norm1.bias", D), D);
+    };
+    for (int l = 0; l < num_blocks && ok; ++l) {
+        const std::string p = "decoder.decoders." + std::to_string(l) + ".";
+        Off& o = offs[l];
+        ffpart(p, o);
+        o.n2g = push(get(p + "norm2.weight", D), D); o.n2b = push(get(p + "norm2.bias", D), D);
+        o.n3g = push(get(p + "norm3.weight", D), D); o.n3b = push(get(p + "norm3.bias", D), D);
+        const float* fw = get(p + "self_attn.fsmn_block.weight", (size_t)D * KS);
+        o.fsmnT = host.size(); host.resize(host.size() + al((size_t)KS * D), 0.f);
+        if (fw) for (int c = 0; c < D; ++c) for (int t = 0; t < KS; ++t) host[o.fsmnT + (size_t)t * D + c] = fw[(size_t)c * KS + t];
+        o.Wq = push(get(p + "src_attn.linear_q.weight", (size_t)D * D), (size_t)D * D); o.bq = push(get(p + "src_attn.linear_q.bias", D), D);
+        o.Wkv = push(get(p + "src_attn.linear_k_v.weight", (size_t)2 * D * D), (size_t)2 * D * D); o.bkv = push(get(p + "src_attn.linear_k_v.bias", 2 * D), 2 * D);
+        o.Wo = push(get(p + "src_attn.linear_out.weight", (size_t)D * D), (size_t)D * D); o.bo = push(get(p + "src_attn.linear_out.bias", D), D);
+    }
+    size_t cifW = 0, cifb = 0, cifw = 0, cifob = 0, ang = 0, anb = 0, Wout = 0, bout = 0;
+    if (ok) {
+        ffpart("decoder.decoders3.0.", offs[num_blocks]);
+        // Conv1d weight [out][in][3] -> [out][tap*512 + in]
+        const float* cw = get("predictor.cif_conv1d.weight", (size_t)D * D * 3);
+        cifW = host.size(); host.resize(host.size() + al((size_t)D * 3 * D), 0.f);
+        if (cw) for (int o_ = 0; o_ < D; ++o_) for (int c = 0; c < D; ++c) for (int j = 0; j < 3; ++j)
+            host[cifW + (size_t)o_ * 3 * D + (size_t)j * D + c] = cw[((size_t)o_ * D + c) * 3 + j];
+        cifb = push(get("predictor.cif_conv1d.bias", D), D);
+        cifw = push(get("predictor.cif_output.weight", D), D);
+        cifob = push(get("predictor.cif_output.bias", 1), 1);
+        ang = push(get("decoder.after_norm.weight", D), D); anb = push(get("decoder.after_norm.bias", D), D);
+        Wout = push(get("decoder.output_layer.weight", (size_t)vocab * D), (size_t)vocab * D, (size_t)vpad * D);     // rows vocab..vpad-1 zero
+        bout = push(get("decoder.output_layer.bias", vocab), vocab, vpad);
+    }
+    if (!ok) return tdx::fail(TDX_E_BLOB, "tdx_pfdec_create: tensor missing or wrong size: " + missing);
+    tdx::DeviceGuard guard(device);
+    hipError_t e = guard.err;
+    if (e != hipSuccess) return tdx::fail_hip(e, __FILE__, __LINE__);
+    float* dev = nullptr;
+    e = hipMalloc(&dev, host.size() * sizeof(float));
+    if (e != hipSuccess) return tdx::fail_hip(e, __FILE__, __LINE__);
+    e = hipMemcpy(dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(dev); return tdx::fail_hip(e, __FILE__, __LINE__); }
+    tdx_pfdec* h = new tdx_pfdec();
+    h->device = device; h->L = num_blocks; h->vocab = vocab; h->vpad = vpad; h->dev = dev;
+    h->layers.resize(num_blocks);
+    struct Job { const float* w; int N, K; PfW3* dst; };
+    std::vector<Job> jobs;
+    auto bind_ff = [&](const Off& o, PfDecLayer& w) {
+        w.b1 = dev + o.b1; w.fg = dev + o.fg; w.fb = dev + o.fb; w.n1g = dev + o.n1g; w.n1b = dev + o.n1b;
+        jobs.push_back({dev + o.W1, FFN, D, &w.h1}); jobs.push_back({dev + o.W2, D, FFN, &w.h2});
+    };
+    for (int l = 0; l < num_blocks; ++l) {
+        const Off& o = offs[l]; PfDecLayer& w = h->layers[l];
+        bind_ff(o, w);
+        w.n2g = dev + o.n2g; w.n2b = dev + o.n2b; w.n3g = dev + o.n3g; w.n3b = dev + o.n3b; w.fsmnT = dev + o.fsmnT;
+        w.bq = dev + o.bq; w.bkv = dev + o.bkv; w.bo = dev + o.bo;
+        jobs.push_back({dev + o.Wq, D, D, &w.hq}); jobs.push_back({dev + o.Wkv, 2 * D, D, &w.hkv}); jobs.push_back({dev + o.Wo, D, D, &w.ho});
+    }
+    bind_ff(offs[num_blocks], h->d3);
+    h->cifb = dev + cifb; h->cifw = dev + cifw; h->cifob = dev + cifob; h->ang = dev + ang; h->anb = dev + anb; h->bout = dev + bout;
+    jobs.push_back({dev + cifW, D, 3 * D, &h->hcif}); jobs.push_back({dev + Wout, vpad, D, &h->hout});
+    size_t bytes = 0;
+    for (const Job& j : jobs) bytes += (size_t)j.N * j.K * 4 + al(j.N) * 4;
+    e = hipMalloc(&h->dev_planes, bytes);
+    if (e != hipSuccess) { hipFree(dev); delete h; return tdx::fail_hip(e, __FILE__, __LINE__); }
+    unsigned char* q = h->dev_planes;
+    for (const Job& j : jobs) {
+        float* sc = (float*)(q + (size_t)j.N * j.K * 4);
+        e = launch_h3_split_rows(j.w, j.K, q, sc, j.N, j.K, nullptr);
+        if (e != hipSuccess) { hipFree(h->dev_planes); hipFree(dev); delete h; return tdx::fail_hip(e, __FILE__, __LINE__); }
+        j.dst->p = q; j.dst->s = sc;
+        q += (size_t)j.N * j.K * 4 + al(j.N) * 4;
+    }
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess) { hipFree(h->dev_planes); hipFree(dev); delete h; return tdx::fail_hip(e, __FILE__, __LINE__); }
+    *out = h;
+    return TDX_OK;
+}
+
+int tdx_pfdec_destroy(tdx_pfdec* h) {
+    if (h) { if (h->dev_planes) hipFree(h->dev_planes); if (h->dev) hipFree(h->dev); delete h; }
+    return TDX_OK;
+}
+
+size_t tdx_pfdec_predict_workspace_bytes(const tdx_pfdec* h, int B, int T) {
+    if (!h || B < 1 || T < 1) return 0;
+    const size_t M = (size_t)B * T;
+    return (al(M * 3 * D) + al(M) + al(M * D)) * sizeof(float);
+}
+
+// enc_dev [B,T,512] -> alphas_dev [B,T+1] (tail frame appended), emb_dev [B,T+1,512] (fired frames first, zero beyond),
+// counts_dev int32 [B] = floor(sum alphas) (the token count of CifPredictorV2), peaks_dev int32 [B,T+1] (frame of fire k, -1 beyond)
+int tdx_pfdec_predict(tdx_pfdec* h, const float* enc, int B, int T, float* alphas, float* emb, int* counts, int* peaks, void* ws_, size_t ws_bytes,
+                      void* stream) {
+    if (!h || !enc || !alphas || !emb || !counts || !peaks || !ws_ || B < 1 || T < 1) return tdx::fail(TDX_E_INVALID, "tdx_pfdec_predict: bad argument");
+    if (ws_bytes < tdx_pfdec_predict_workspace_bytes(h, B, T)) return tdx::fail(TDX_E_WORKSPACE, "tdx_pfdec_predict: workspace too small");
+    if ((size_t)(T + 1) * 12 > 60000) return tdx::fail(TDX_E_INVALID, "tdx_pfdec_predict: T too large for the CIF kernel's LDS (T <= 4999)");
+    tdx::DeviceGuard guard(h->device);
+    if (guard.err != hipSuccess) return tdx::fail_hip(guard.err, __FILE__, __LINE__);
+    hipStream_t st = (hipStream_t)stream;
+    const long M = (long)B * T;
+    unsigned char* hp = (unsigned char*)ws_;
+    float* hs = (float*)ws_ + al(M * 3 * D);
+    float* p1 = hs + al(M);
+    const dim3 rows4((unsigned)((M + 3) / 4));
+    hipLaunchKernelGGL(pf_im2col3_planes_kernel, rows4, dim3(256), 0, st, enc, hp, hs, M, T);
+    LAUNCH_CHECK();
+    TRY(lin3(hp, hs, h->hcif, (int)M, D, 3 * D, EpiCifConv{h->cifb, enc, p1}, st));
+    hipLaunchKernelGGL(pf_alpha_kernel, rows4, dim3(256), 0, st, p1, h->cifw, h->cifob, alphas, M, T);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(pf_cif_kernel, dim3(B), dim3(512), (size_t)(T + 1) * 12, st, enc, alphas, emb, counts, peaks, T);
+    LAUNCH_CHECK();
+    return TDX_OK;
+}
+
+size_t tdx_pfdec_decode_workspace_bytes(const tdx_pfdec* h, int B, int L, int T) {
+    if (!h || B < 1 || L < 1 || T < 1) return 0;
+    const size_t M = (size_t)B * L, MT = (size_t)B * T, Tp = (size_t)(T + 127) / 128 * 128;
+    return (al(M * D) * 5 + al(M * FFN) * 2 + al(M) + al(MT * D) + al(MT) + al((MT + 128) * 2 * D) + al((size_t)B * H * L * Tp) + al((M + 128) * D) +
+            al(M * (size_t)h->vpad)) * sizeof(float);
+}
+
+// emb_dev: [B][emb_rows][512] (the predictor's output, emb_rows = T+1; the first L rows of each utterance are used),
+// counts_dev int32 [B] (tokens per utterance; rows beyond are masked), enc_dev [B,T,512] -> ids_dev int32 [B,L], score_dev [B,L] or NULL
+int tdx_pfdec_decode(tdx_pfdec* h, const float* emb, int emb_rows, const int* counts, const float* enc, int B, int L, int T, int* ids, float* score,
+                     void* ws_, size_t ws_bytes, void* stream) {
+    if (!h || !emb || !counts || !enc || !ids || !ws_ || B < 1 || L < 1 || T < 1 || emb_rows < L) return tdx::fail(TDX_E_INVALID, "tdx_pfdec_decode: bad argument");
+    if (ws_bytes < tdx_pfdec_decode_workspace_bytes(h, B, L, T)) return tdx::fail(TDX_E_WORKSPACE, "tdx_pfdec_decode: workspace too small");
+    tdx::DeviceGuard guard(h->device);
+    if (guard.err != hipSuccess) return tdx::fail_hip(guard.err, __FILE__, __LINE__);
+    hipStream_t st = (hipStream_t)stream;
+    const long M = (long)B * L, MT = (long)B * T;
+    const int Tp = (T + 127) / 128 * 128;
+    float* ws = (float*)ws_;
+    float* x = ws; float* tgt = x + al(M * D); float* t2 = tgt + al(M * D); float* memt = t2 + al(M * D); float* q = memt + al(M * D);
+    float* ffn = q + al(M * D);
+    unsigned char* hp = (unsigned char*)(ffn + al(M * FFN));
+    float* hs = (float*)hp + al(M * FFN);
+    unsigned char* encP = (unsigned char*)(hs + al(M));
+    float* encS = (float*)encP + al(MT * D);
+    float* kv = encS + al(MT);
+    float* sc = kv + al((MT + 128) * 2 * D);
+    float* ctx = sc + al((size_t)B * H * L * Tp);
+    float* logits = ctx + al((M + 128) * D);
+    const dim3 rows4((unsigned)((M + 3) / 4));
+    if (hipMemcpy2DAsync(x, (size_t)L * D * 4, emb, (size_t)emb_rows * D * 4, (size_t)L * D * 4, B, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    if (launch_h3_split_rows(enc, D, encP, encS, MT, D, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    auto ffn_block = [&](const PfDecLayer& w, const float* in, float* outp) -> int {      // w_2(LN(relu(w_1(LN(in)))))
+        hipLaunchKernelGGL(pf_layernorm_planes_kernel_t<2>, rows4, dim3(256), 0, st, in, (long)D, D, w.n1g, w.n1b, hp, hs, D, M, PF_LN_EPS);
+        LAUNCH_CHECK();
+        TRY(lin3(hp, hs, w.h1, (int)M, FFN, D, EpiBiasReluP{w.b1, ffn, FFN}, st));
+        hipLaunchKernelGGL(pf_layernorm_planes_kernel_t<4>, rows4, dim3(256), 0, st, ffn, (long)FFN, FFN, w.fg, w.fb, hp, hs, FFN, M, PF_LN_EPS);
+        LAUNCH_CHECK();
+        TRY(lin3(hp, hs, w.h2, (int)M, D, FFN, EpiStoreP{outp, D}, st));
+        return TDX_OK;
+    };
+    for (int l = 0; l < h->L; ++l) {
+        const PfDecLayer& w = h->layers[l];
+        TRY(ffn_block(w, x, tgt));
+        // ---- FSMN memory block: x = x + mask * (t2 + dwconv11(t2)), t2 = mask * LN(tgt)
+        hipLaunchKernelGGL(pf_layernorm_mask_kernel, rows4, dim3(256), 0, st, tgt, w.n2g, w.n2b, t2, M, L, counts, PF_LN_EPS);
+        LAUNCH_CHECK();
+        {
+            Conv17Args a{};
+            a.in = t2; a.ld_in = D; a.col0 = 0; a.wT = w.fsmnT; a.C = D; a.out = memt; a.ld_out = D; a.S = L; a.Sp = L;
+            dim3 block(128, 2), grid(1, (L + 2 * 128 - 1) / (2 * 128), B);
+            hipLaunchKernelGGL((conv17_kernel<0, 128, KS>), grid, block, 0, st, a);
+            LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(pf_add_masked_kernel, dim3((unsigned)((M * (D / 4) + 255) / 256)), dim3(256), 0, st, x, memt, M, L, counts);
+        LAUNCH_CHECK();
+        // ---- cross attention on the encoder output: x += W_o softmax(q k^T / sqrt(dk)) v + b_o
+        hipLaunchKernelGGL(pf_layernorm_planes_kernel_t<2>, rows4, dim3(256), 0, st, x, (long)D, D, w.n3g, w.n3b, hp, hs, D, M, PF_LN_EPS);
+        LAUNCH_CHECK();
+        TRY(lin3(hp, hs, w.hq, (int)M, D, D, EpiBiasP{w.bq, q, D}, st));
+        TRY(lin3(encP, encS, w.hkv, (int)MT, 2 * D, D, EpiBiasP{w.bkv, kv, 2 * D}, st));
+        {
+            GemmSeg s = make_seg(q, D, kv, 2 * D, DK, (long)L * D, (long)T * 2 * D);
+            s.zdiv = H; s.strideA2 = DK; s.strideB2 = DK;
+            GemmArgs g = make_args(L, Tp, s);
+            if (launch_gemm<false, false, false, false>(g, B * H, EpiScoresR{sc, L, Tp, 0.08838834764831845f}, st) != hipSuccess)
+                return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+        }
+        hipLaunchKernelGGL(pf_softmax_rect_kernel, dim3((L + 3) / 4, B * H), dim3(256), 0, st, sc, L, T, Tp);
+        LAUNCH_CHECK();
+        {
+            GemmSeg s = make_seg(sc, Tp, kv + D, 2 * D, Tp, (long)L * Tp, 0, T);
+            GemmArgs g = make_args(L, DK, s);
+            g.seg[0].zdiv = H; g.seg[0].strideA = (long)H * L * Tp; g.seg[0].strideA2 = (long)L * Tp;
+            g.seg[0].strideB = (long)T * 2 * D; g.seg[0].strideB2 = DK; g.seg[0].kchunk = 0; g.seg[0].ktotal = T;
+            if (launch_gemm<false, true, false, false>(g, B * H, EpiCtx{ctx, L}, st) != hipSuccess)
+                return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+        }
+        if (launch_h3_split_rows(ctx, D, hp, hs, M, D, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+        TRY(lin3(hp, hs, w.ho, (int)M, D, D, EpiBiasResP{w.bo, x, D}, st));
+    }
+    TRY(ffn_block(h->d3, x, tgt));                      // decoders3: FFN only, no residual
+    hipLaunchKernelGGL(pf_layernorm_planes_kernel_t<2>, rows4, dim3(256), 0, st, tgt, (long)D, D, h->ang, h->anb, hp, hs, D, M, PF_LN_EPS);
+    LAUNCH_CHECK();
+    TRY(lin3(hp, hs, h->hout, (int)M, h->vpad, D, EpiBiasP{h->bout, logits, h->vpad}, st));
+    hipLaunchKernelGGL(pf_argmax_kernel, rows4, dim3(256), 0, st, logits, (long)h->vpad, h->vocab, ids, score, M);
     LAUNCH_CHECK();
     return TDX_OK;
 }

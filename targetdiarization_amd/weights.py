@@ -186,6 +186,62 @@ def recipe_paraformer_state_dict(seed: int = 0, num_blocks: int = 50) -> "Ordere
     return out
 
 
+def paraformer_decoder_param_shapes(num_blocks: int = 16, d: int = 512, ffn: int = 2048, ksize: int = 11,
+                                    vocab: int = 8404) -> "OrderedDict[str, tuple]":
+    """funasr Paraformer (CifPredictorV2 + ParaformerSANMDecoder) state_dict layout [upstream-recall, SURVEY Appendix B.4]:
+    predictor conv/linear, `decoders.{i}` (FFN -> FSMN memory -> cross attention), one FFN-only `decoders3.0`, after_norm,
+    output_layer.  (`decoder.embed` is unused by the non-autoregressive forward and not part of the recipe.)"""
+    s = OrderedDict()
+    s["predictor.cif_conv1d.weight"] = (d, d, 3)
+    s["predictor.cif_conv1d.bias"] = (d,)
+    s["predictor.cif_output.weight"] = (1, d)
+    s["predictor.cif_output.bias"] = (1,)
+
+    def ff(p):
+        s[p + "feed_forward.w_1.weight"] = (ffn, d)
+        s[p + "feed_forward.w_1.bias"] = (ffn,)
+        s[p + "feed_forward.w_2.weight"] = (d, ffn)
+        s[p + "feed_forward.norm.weight"] = (ffn,)
+        s[p + "feed_forward.norm.bias"] = (ffn,)
+        s[p + "norm1.weight"] = (d,)
+        s[p + "norm1.bias"] = (d,)
+
+    for i in range(num_blocks):
+        p = f"decoder.decoders.{i}."
+        ff(p)
+        s[p + "self_attn.fsmn_block.weight"] = (d, 1, ksize)
+        s[p + "norm2.weight"] = (d,); s[p + "norm2.bias"] = (d,)
+        s[p + "src_attn.linear_q.weight"] = (d, d); s[p + "src_attn.linear_q.bias"] = (d,)
+        s[p + "src_attn.linear_k_v.weight"] = (2 * d, d); s[p + "src_attn.linear_k_v.bias"] = (2 * d,)
+        s[p + "src_attn.linear_out.weight"] = (d, d); s[p + "src_attn.linear_out.bias"] = (d,)
+        s[p + "norm3.weight"] = (d,); s[p + "norm3.bias"] = (d,)
+    ff("decoder.decoders3.0.")
+    s["decoder.after_norm.weight"] = (d,)
+    s["decoder.after_norm.bias"] = (d,)
+    s["decoder.output_layer.weight"] = (vocab, d)
+    s["decoder.output_layer.bias"] = (vocab,)
+    return s
+
+
+def recipe_paraformer_decoder_state_dict(seed: int = 0, num_blocks: int = 16, vocab: int = 8404) -> "OrderedDict[str, torch.Tensor]":
+    out = OrderedDict()
+    for name, shape in paraformer_decoder_param_shapes(num_blocks, vocab=vocab).items():
+        n = int(np.prod(shape))
+        u = torch.from_numpy(philox_uniform("pfd:" + name, n, seed)).reshape(shape)
+        leaf = name.rsplit(".", 1)[-1]
+        if "norm" in name:
+            t = (1.0 + 0.2 * u) if leaf == "weight" else 0.1 * u
+        elif name == "predictor.cif_output.bias":
+            t = torch.full(shape, -1.0)                      # sigmoid around 0.27: one token per ~4 encoder frames
+        elif leaf == "bias":
+            t = 0.1 * u
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            t = u * float(np.sqrt(3.0 / fan_in))
+        out[name] = t.to(torch.float32).contiguous()
+    return out
+
+
 def eres2netv2_param_shapes(m: int = 64, feat_dim: int = 80, emb: int = 192, base_width: int = 24, scale: int = 4,
                             expansion: int = 4, num_blocks=(3, 4, 6, 3)) -> "OrderedDict[str, tuple]":
     """3D-Speaker ERes2NetV2 state_dict layout [upstream-recall, SURVEY Appendix B.3]."""

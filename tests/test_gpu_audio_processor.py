@@ -60,3 +60,43 @@ def test_degrade_semantics(sd2):
     assert a is x and b is x
     ap2 = AudioProcessor(is_separate_audio=True, separater_weights_folder="/nonexistent", verbose_log=False)
     assert ap2.is_separate_audio is False            # init failure flips the flag, never raises   :189-193
+
+
+def test_low_gpu_ram_vad_plan_matches_reference_loop(sd2):
+    """low_gpu_ram (AudioProcessor.py:892-917): 1 s windows inside silero-VAD frames (a plug-in here), zeros before / between the
+    frames, nothing after the last one.  Oracle = the reference's loop restated with batch 1 per window."""
+    from oracle import mossformer2_oracle as orc
+    from targetdiarization_amd.audio_processor import AudioProcessor
+    from targetdiarization_amd.loudness import integrated_loudness
+    from targetdiarization_amd.weights import recipe_wave
+    audio = recipe_wave("lowram", 1, 120000)[0]
+    frames = [[3000, 40000], [52000, 100001]]
+    ap = AudioProcessor(is_separate_audio=True, separater_state_dict=sd2, cuda_device=0, verbose_log=False, silero_vad=lambda a: frames)
+    a, b = ap.separate_speaker(audio, 16000, low_gpu_ram=True)
+    s1, s2 = np.array([], np.float32), np.array([], np.float32)
+    for i, (f0, f1) in enumerate(frames):                          # :908-948
+        if f0 > s1.shape[0]:
+            gap = np.zeros(f0 if i == 0 else f0 - frames[i - 1][1], np.float32)
+            s1, s2 = np.concatenate([s1, gap]), np.concatenate([s2, gap])
+        for (w0, w1) in orc.window_plan(f1 - f0, 16000, f0):
+            y = orc.mossformer2_forward(torch.from_numpy(audio[w0:w1].copy())[None], sd2)[0].numpy()
+            s1, s2 = np.concatenate([s1, y[0]]), np.concatenate([s2, y[1]])
+    if round(integrated_loudness(s1, 16000), 1) < round(integrated_loudness(s2, 16000), 1):
+        s1, s2 = s2, s1
+    assert a.shape == s1.shape == (100001,)                        # the tail after the last VAD frame is dropped, like the reference
+    assert np.all(a[:3000] == 0) and np.all(a[40000:52000] == 0)
+    assert np.linalg.norm(a - s1) / np.linalg.norm(s1) < 1e-4 and np.linalg.norm(b - s2) / np.linalg.norm(s2) < 1e-4
+
+
+def test_separate_speaker_resamples_in_and_out(sd2):
+    """a rate other than 16 kHz is resampled in and back out (:889-891, :953-955)"""
+    from targetdiarization_amd.audio_processor import AudioProcessor
+    from targetdiarization_amd.weights import recipe_wave
+    audio8k = recipe_wave("sr8k", 1, 20000)[0]
+    ap = AudioProcessor(is_separate_audio=True, separater_state_dict=sd2, cuda_device=0, verbose_log=False)
+    a, b = ap.separate_speaker(audio8k, 8000)
+    x16 = ap.audio_resample(audio8k, 8000, 16000, output_audio_only=True)
+    r1, r2 = ap.separate_speaker(x16, 16000)
+    e1 = ap.audio_resample(r1, 16000, 8000, output_audio_only=True)
+    assert a.shape == e1.shape == (20000,) and a.dtype == np.float32
+    assert np.linalg.norm(a - e1) / np.linalg.norm(e1) < 1e-5

@@ -1,5 +1,6 @@
 """-m gpu: Paraformer SANM encoder vs its oracle (parity unpinned: third-party
 architecture restated from upstream, recipe weights).  Tolerance 1e-4 rel-L2 / 1e-3 cosine."""
+import numpy as np
 import pytest
 import torch
 

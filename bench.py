@@ -8,8 +8,9 @@ A "step" is one pass of the hot path over one batch of synthetic audio that is a
 (utterances go up before the timed region; results stay on the device, DESIGN.md §5 gives the PCIe-inclusive
 rate).  The pipe per step: MossFormer2 separation (H1, 10 s windows) -> louder-stream-first swap (BS.1770 on
 the device) -> ERes2NetV2 embeddings of the separated streams + all-gather + cosine scores against a target
-embedding (H2) -> Paraformer SANM encoder on <= 30 s segments of both streams (H3), punctuation = host
-pass-through.  24-block MossFormer2 / ERes2NetV2-w24s4ep4 / 50-layer encoder at the reference's model sizes,
+embedding (H2) -> Paraformer on <= 30 s segments of both streams (H3: SANM encoder, CIF predictor, NAR decoder,
+argmax tokens + timestamps), punctuation = host pass-through.  24-block MossFormer2 / ERes2NetV2-w24s4ep4 /
+50-layer encoder + 16-layer decoder at the reference's model sizes,
 recipe (random-init) weights, fp32-accurate arithmetic.
 
   N = 1 (default)  BASELINE configs[3]: one 1800 s synthetic conversation = 180 windows, embeddings per 10 s
@@ -137,14 +138,15 @@ def cpu_baseline_pipe(sep_sd, spk_sd, asr_sd, window_np, with_asr: bool):
         if with_asr:
             for k in range(2):
                 feats = fo.asr_features(y[k], torch.zeros(560), torch.ones(560))
-                po.sanm_encoder_forward(feats[None], asr_sd)
-        t3 = time.perf_counter(); stages["asr_encoder"] = t3 - t2
+                enc = po.sanm_encoder_forward(feats[None], asr_sd)
+                po.paraformer_decode(enc, asr_sd)
+        t3 = time.perf_counter(); stages["asr_encoder+decoder"] = t3 - t2
         dt = t3 - t0
     secs = window_np.shape[0] / 16000.0
     return {"value": secs / dt, "unit": "audio-s/s", "cores": cores, "kind": "port",
             "sample": f"one [1,{window_np.shape[0]}] window of the same synthetic recording through the oracle chain "
                       f"(oracle/mossformer2_oracle.py -> frontend_oracle + eres2netv2_oracle on both streams + cosine"
-                      + (" -> frontend_oracle + paraformer_oracle encoder on both streams" if with_asr else "")
+                      + (" -> frontend_oracle + paraformer_oracle encoder + CIF + decoder on both streams" if with_asr else "")
                       + f"), batch 1 per call like the reference, torch CPU fp32, {dt:.1f}s wall",
             "stage_seconds": stages}
 
@@ -159,8 +161,8 @@ def dist_env():
 def pipe_bench(args):
     import torch.distributed as dist
     from targetdiarization_amd.pipeline import HotPath, shard_indices
-    from targetdiarization_amd.weights import (recipe_eres2netv2_state_dict, recipe_paraformer_state_dict,
-                                               recipe_state_dict)
+    from targetdiarization_amd.weights import (recipe_eres2netv2_state_dict, recipe_paraformer_decoder_state_dict,
+                                               recipe_paraformer_state_dict, recipe_state_dict)
     rank, local_rank, world = dist_env()
     use_dist = world > 1
     if use_dist:
@@ -171,7 +173,9 @@ def pipe_bench(args):
     wl = args.workload
     with_asr = wl != "cfg3"
     sep_sd, spk_sd = recipe_state_dict(0, 24), recipe_eres2netv2_state_dict(0)
-    asr_sd = recipe_paraformer_state_dict(0, 50) if with_asr else None
+    asr_sd = None
+    if with_asr:                                  # 50-layer SANM encoder + CIF predictor + 16-layer NAR decoder (vocabulary 8404)
+        asr_sd = dict(recipe_paraformer_state_dict(0, 50)); asr_sd.update(recipe_paraformer_decoder_state_dict(0, 16))
     hp = HotPath(sep_sd, spk_sd, asr_sd, cuda_device=local_rank, windows_per_launch=args.windows_per_launch)
     target = torch.from_numpy(np.random.default_rng(5).standard_normal(192).astype(np.float32)).to(dev)
 
@@ -186,7 +190,7 @@ def pipe_bench(args):
         windows_local = nwin
         desc = (f"BASELINE {'configs[2]' if wl == 'cfg3' else 'configs[3]'}: {total_s} s synthetic conversation = {nwin} x 10 s windows: "
                 f"MossFormer2 ({args.windows_per_launch} windows per launch) -> loudness swap -> ERes2NetV2 on every 10 s window of both streams "
-                "+ cosine vs a target embedding" + (" -> Paraformer SANM encoder on 30 s segments of both streams, punctuation pass-through" if with_asr else "")
+                "+ cosine vs a target embedding" + (" -> Paraformer (SANM encoder, CIF predictor, NAR decoder, argmax tokens + timestamps) on 30 s segments of both streams, punctuation pass-through" if with_asr else "")
                 + "; recipe weights, device-resident")
         sample_window = rec_np[:WINDOW]
     else:   # cfg5
@@ -204,7 +208,7 @@ def pipe_bench(args):
         desc = (f"BASELINE configs[4]: the {n_job} x 30 s utterance job in batches of {per_step} utterances (one step = one batch, "
                 f"utterance i of a batch on rank i % {world}; strong scaling: the batch does not grow with N): MossFormer2 (3 windows per "
                 "utterance) -> loudness swap -> ERes2NetV2 on both streams -> all-gather of the [n_i*2,192] embedding blocks (RCCL) -> cosine "
-                "scores -> Paraformer SANM encoder on both streams; recipe weights, device-resident")
+                "scores -> Paraformer (SANM encoder, CIF predictor, NAR decoder) on both streams; recipe weights, device-resident")
         sample_window = None
 
     def step(k):
@@ -255,11 +259,11 @@ def pipe_bench(args):
         ops.cosine_scores(hp.spk.embed_device(clips), target)
         ev[2].record()
         if with_asr:
-            hp.encode_device(flat)
+            hp.encode_device(flat, decode=True)
         ev[3].record()
         torch.cuda.synchronize(dev)
         stage_ms = {"separation+loudness": ev[0].elapsed_time(ev[1]), "embedding+cosine": ev[1].elapsed_time(ev[2]),
-                    "asr_encoder": ev[2].elapsed_time(ev[3]) if with_asr else 0.0}
+                    "asr_encoder+decoder": ev[2].elapsed_time(ev[3]) if with_asr else 0.0}
     if use_dist:
         dist.barrier()
 
@@ -306,7 +310,7 @@ def pipe_bench(args):
                          "whole_path_frac": sum(fl.values()) * args.steps / dt / 1e12 / PEAK_H3_TFLOPS},
             "stage_ms_per_step_rank0": stage_ms,
             "stage_tflops_rank0": {k: (fl[a] / (stage_ms[k] * 1e-3) / 1e12 if stage_ms[k] > 0 else None)
-                                   for k, a in (("separation+loudness", "separation"), ("embedding+cosine", "embedding"), ("asr_encoder", "asr_encoder"))},
+                                   for k, a in (("separation+loudness", "separation"), ("embedding+cosine", "embedding"), ("asr_encoder+decoder", "asr_encoder"))},
             "algorithmic_flops_per_step_rank0": fl,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -62,9 +62,13 @@ class HotPath:
         if spk_state_dict is not None:
             from .speaker import SpeakerEmbedder
             self.spk = SpeakerEmbedder(spk_state_dict, cuda_device)
+        self.dec = None
         if asr_state_dict is not None:
-            from .paraformer import ParaformerEncoder
-            self.asr = ParaformerEncoder(asr_state_dict, self.device, cmvn_shift=cmvn_shift, cmvn_scale=cmvn_scale)
+            from .paraformer import ParaformerDecoder, ParaformerEncoder
+            enc_sd = {k: v for k, v in asr_state_dict.items() if k.startswith("encoder.")}
+            self.asr = ParaformerEncoder(enc_sd, self.device, cmvn_shift=cmvn_shift, cmvn_scale=cmvn_scale)
+            if any(k.startswith("decoder.decoders.") for k in asr_state_dict):       # CIF predictor + NAR decoder (N2)
+                self.dec = ParaformerDecoder(asr_state_dict, self.device)
         self.asr_segment = asr_segment
         self.windows_per_launch = windows_per_launch
         self.asr_rows_per_launch = asr_rows_per_launch
@@ -102,9 +106,11 @@ class HotPath:
         return self.spk.get_speaker_embeddings(streams)
 
     # ---- H3 -------------------------------------------------------------------------------
-    def encode_device(self, streams):
+    def encode_device(self, streams, decode: bool = False):
         """Paraformer encoder outputs per stream: list of [T_i,512] DEVICE tensors (segments <= 30 s,
-        equal-length segments batched, <= asr_rows_per_launch LFR frames per launch sequence)."""
+        equal-length segments batched, <= asr_rows_per_launch LFR frames per launch sequence).
+        decode=True (needs the decoder weights): also the CIF + NAR decoder results of every segment, as
+        (encoder outputs, [per stream: list of {"token_ids","scores","timestamp"} per segment, timestamps offset to the stream])."""
         streams = [self._dev(s) for s in streams]
         segs, owner = [], []
         for si, s in enumerate(streams):
@@ -113,6 +119,10 @@ class HotPath:
                 if seg.shape[0] >= 400:
                     segs.append(seg); owner.append(si)
         outs = [None] * len(segs)
+        decs = [None] * len(segs)
+        if decode and self.dec is None:
+            from ._lib import TdxError
+            raise TdxError("decode=True needs the predictor/decoder tensors in asr_state_dict")
         by_len = {}
         for i, s in enumerate(segs):
             by_len.setdefault(int(s.shape[0]), []).append(i)
@@ -122,12 +132,21 @@ class HotPath:
             for c in range(0, len(idxs), step):
                 chunk = idxs[c:c + step]
                 y = self.asr(torch.stack([segs[i] for i in chunk]))
+                d = self.dec.decode(y) if decode else None
                 for j, i in enumerate(chunk):
                     outs[i] = y[j]
+                    if decode:
+                        decs[i] = d[j]
         res = [[] for _ in streams]
+        dres = [[] for _ in streams]
         for i, si in enumerate(owner):
             res[si].append(outs[i])
-        return [(r[0] if len(r) == 1 else torch.cat(r, dim=0)) if r else torch.zeros(0, 512, device=self.device) for r in res]
+            if decode:
+                off_ms = len(dres[si]) * self.asr_segment / 16.0            # segment start inside the stream, ms
+                r = dict(decs[i]); r["timestamp"] = [[a + off_ms, b + off_ms] for a, b in r["timestamp"]]
+                dres[si].append(r)
+        enc = [(r[0] if len(r) == 1 else torch.cat(r, dim=0)) if r else torch.zeros(0, 512, device=self.device) for r in res]
+        return (enc, dres) if decode else enc
 
     def encode_streams(self, streams):
         """host form: list of [T_i,512] numpy arrays"""
@@ -170,7 +189,10 @@ class HotPath:
                 tgt = target_embedding if isinstance(target_embedding, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(target_embedding, dtype=np.float32))
                 out["scores"] = ops.cosine_scores(allemb, tgt.to(self.device, torch.float32)) if allemb.shape[0] else torch.zeros(0, device=self.device)
         if self.asr is not None and with_asr:
-            out["encoder"] = self.encode_device(flat)
+            if self.dec is not None:
+                out["encoder"], out["asr"] = self.encode_device(flat, decode=True)      # tokens + timestamps per <= 30 s segment
+            else:
+                out["encoder"] = self.encode_device(flat)
         if to_host:                                   # the one D2H of the path
             out["streams"] = [(p[0].cpu().numpy(), p[1].cpu().numpy()) for p in sep]
             for k in ("embeddings", "scores"):

@@ -325,6 +325,51 @@ def pipe_bench(args):
 
 
 # ----------------------------------------------------------------------------------------------
+# cfg1: the reference's own CPU-runnable case (BASELINE configs[0]) — the hot-path subset of infer() on the two asset clips,
+# host arrays in, host arrays out, ONE window per call (what a user of the drop-in API sees)
+# ----------------------------------------------------------------------------------------------
+def cfg1_bench(args):
+    import wave as wavmod
+    from targetdiarization_amd.pipeline import HotPath
+    from targetdiarization_amd.weights import (recipe_eres2netv2_state_dict, recipe_paraformer_decoder_state_dict,
+                                               recipe_paraformer_state_dict, recipe_state_dict)
+
+    def load(fn):
+        with wavmod.open(os.path.join(ROOT, "tests", "golden", fn), "rb") as w:
+            return np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).astype(np.float32) / 32768.0
+    mix, tgt = load("chat_mix.wav"), load("female_a.wav")
+    torch.cuda.set_device(0)
+    asr_sd = dict(recipe_paraformer_state_dict(0, 50)); asr_sd.update(recipe_paraformer_decoder_state_dict(0, 16))
+    hp = HotPath(recipe_state_dict(0, 24), recipe_eres2netv2_state_dict(0), asr_sd, cuda_device=0)
+
+    def step():
+        # H2 on the target clip || H1 (one 8.665 s window) -> H2 on both streams + cosine || H3 on both streams
+        return hp.run([mix], target_clip=tgt)
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        hp.separate([mix])
+    torch.cuda.synchronize()
+    dsep = time.perf_counter() - t1
+    secs = len(mix) / 16000.0
+    print(json.dumps({"metric": METRIC + " — hot-path subset of BASELINE configs[0]", "value": secs * args.steps / dt, "unit": "audio-s/s", "n_gpus": 1,
+                      "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                      "vs_baseline": None, "dtype": DTYPE, "data": "reference assets (chat_mix.wav 8.665 s + female_a.wav 1.923 s), recipe weights",
+                      "config": {"workload": "BASELINE configs[0] hot-path subset: host arrays in/out, batch 1: MossFormer2 on the mix as ONE window (S = 17 328, "
+                                             "HIP-graph replay) -> ERes2NetV2 on the target clip and both separated streams + cosine -> Paraformer encoder + CIF + "
+                                             "decoder on both streams"},
+                      "separation_only_ms": dsep / args.steps * 1e3, "separation_only_rtf": secs * args.steps / dsep,
+                      "tokens_stream0": len(out["asr"][0][0]["token_ids"])}), flush=True)
+
+
+# ----------------------------------------------------------------------------------------------
 # cfg2: MossFormer2 only (BASELINE configs[1]) — H1 kernel measurement
 # ----------------------------------------------------------------------------------------------
 def cfg2_bench(args):
@@ -470,7 +515,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default=None, choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+    ap.add_argument("--workload", default=None, choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"],
                     help="default: cfg4 (BASELINE configs[3], the full pipe on 1800 s) at one GPU, cfg5 (BASELINE configs[4], the "
                          "1000-utterance job, strong scaling) at more; cfg2 = MossFormer2 only; cfg3 = 600 s without the ASR encoder")
     ap.add_argument("--windows-per-launch", type=int, default=30, help="10 s windows per MossFormer2 launch sequence")
@@ -492,6 +537,8 @@ def main():
         return dry_run(args)
     if args.workload is None:
         args.workload = "cfg4" if world == 1 else "cfg5"
+    if args.workload == "cfg1":
+        return cfg1_bench(args)
     if args.workload == "cfg2":
         return cfg2_bench(args)
     return pipe_bench(args)

@@ -25,8 +25,8 @@ int tdx_h3_gemm(const void* pa, const float* sa, const void* pb, const float* sb
                 int M, int N, int K, void* stream);
 /* timing variants of the x3 main loop (gemm_h3.hpp VARIANT: 0 product, 1 no loads, 2 no fragment reads, 3 neither,
  * 4 no barrier, 5 ping-pong, 6 v_mfma_f32_16x16x32_f16 instead of 32x32x16 (same flops), 9 loads never waited for;
- * 10 = the narrow kernel gemm_h3n.hpp (256 x 128 tile, two blocks per CU), 16 = narrow + 16x16x32); only 0, 5 and 10
- * produce correct results */
+ * 10 = the narrow kernel gemm_h3n.hpp (256 x 128 tile, two blocks per CU), 16 = narrow + 16x16x32 (timing only),
+ * 20 = the pair-stage kernel gemm_h3p.hpp (16x16x32 MFMA, correct results)); only 0, 5, 10 and 20 produce correct results */
 int tdx_h3_gemm_variant(const void* pa, const float* sa, const void* pb, const float* sb, const float* bias_dev,
                         float* c_dev, int M, int N, int K, int variant, void* stream);
 /* timing variants of the fp32-MFMA core (gemm.hpp VARIANT) and the x6 core (variant 6) */

@@ -193,7 +193,10 @@ __global__ __launch_bounds__(256) void rowscale_split_kernel(const float* __rest
 // GEMM epilogues / conv17<1> keep x in (xs[h*M + m], xss[h*M + m]); one wave per (row, half).  Used once per forward
 // (x after the positional encoding); inside the stack the producers write the planes themselves.
 __global__ __launch_bounds__(256) void xplanes_kernel(const float* __restrict__ x, unsigned char* __restrict__ xp, float* __restrict__ xs,
-                                                       float* __restrict__ xss, long M) {
+                                                       float* __restrict__ xss, long M, float* __restrict__ zrow) {
+    if (blockIdx.x == 0) {      // the zero planes row of the token shift (1024 floats), written here instead of a memset node
+        for (int j = threadIdx.x; j < 1024; j += 256) zrow[j] = 0.f;
+    }
     const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= 2 * M) return;
     const long m = i >> 1;

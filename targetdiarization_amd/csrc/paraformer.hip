@@ -178,6 +178,18 @@ int lin3(const unsigned char* Ap, const float* As, const PfW3& W, int M, int N, 
     return TDX_OK;
 }
 
+// the same Linear on the exact-fp32 MFMA core (gemm.hpp: 128x128x32 tiles, 3 blocks per CU), meant for SMALL row counts (one clip per
+// call has a few hundred rows; a single x3 tile then walks its whole K loop alone, K = 2048: 128 stages ~ 190 us).  MEASURED at
+// config 1 (2 x 145 LFR frames): SLOWER than the x3 path (50-layer encoder 24.4 vs 18.8 ms, decoder 7.8 vs 5.6 ms) — the fp32 core's
+// 64 k-steps of K = 2048 are no shorter.  Kept switchable for the record; 0 = off.  A fp32 [M][lda], W fp32 [N][K].
+constexpr long PF_SMALL_ROWS = 0;
+template <class Epi>
+int lin_small(const float* A, long lda, const float* W, int M, int N, int K, Epi e, hipStream_t st) {
+    GemmArgs g = make_args(M, N, make_seg(A, lda, W, K, K));
+    if (launch_gemm<false, false, false, false>(g, 1, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    return TDX_OK;
+}
+
 }  // namespace
 
 struct tdx_pfenc {
@@ -311,6 +323,7 @@ int tdx_pfenc_forward(tdx_pfenc* h, const float* feats, const int* lens_host, in
     unsigned char* hp = (unsigned char*)(ffn + al(M * FFN));
     float* hs = (float*)hp + al(M * FFN);
     const dim3 rows4((unsigned)((M + 3) / 4));
+    const bool small = M <= PF_SMALL_ROWS;          // few rows: Linears on the exact-fp32 core (see lin_small)
 
     hipLaunchKernelGGL(pf_embed_kernel, dim3(T, B), dim3(256), 0, st, feats, xin, T);
     LAUNCH_CHECK();
@@ -321,9 +334,15 @@ int tdx_pfenc_forward(tdx_pfenc* h, const float* feats, const int* lens_host, in
         const long ldx = first ? DINP : D;
         const int din = first ? DIN : D, dinp = first ? DINP : D;
         // ---- x̂ = LN(x) ; [q|k|v] = x̂ W^T + b
-        hipLaunchKernelGGL(pf_layernorm_planes_kernel, rows4, dim3(256), 0, st, xl, ldx, din, w.n1g, w.n1b, hp, hs, dinp, M, PF_LN_EPS);
-        LAUNCH_CHECK();
-        TRY(lin3(hp, hs, w.hqkv, (int)M, 3 * D, dinp, EpiBiasP{w.bqkv, qkv, 3 * D}, st));
+        if (small) {
+            hipLaunchKernelGGL(pf_layernorm_kernel, rows4, dim3(256), 0, st, xl, ldx, din, w.n1g, w.n1b, hbuf, (long)dinp, dinp, M, PF_LN_EPS);
+            LAUNCH_CHECK();
+            TRY(lin_small(hbuf, dinp, w.Wqkv, (int)M, 3 * D, dinp, EpiBiasP{w.bqkv, qkv, 3 * D}, st));
+        } else {
+            hipLaunchKernelGGL(pf_layernorm_planes_kernel, rows4, dim3(256), 0, st, xl, ldx, din, w.n1g, w.n1b, hp, hs, dinp, M, PF_LN_EPS);
+            LAUNCH_CHECK();
+            TRY(lin3(hp, hs, w.hqkv, (int)M, 3 * D, dinp, EpiBiasP{w.bqkv, qkv, 3 * D}, st));
+        }
         // ---- FSMN memory: v + dwconv11(v)
         {
             Conv17Args a{};
@@ -353,6 +372,14 @@ int tdx_pfenc_forward(tdx_pfenc* h, const float* feats, const int* lens_host, in
                 return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
         }
         // ---- x = (residual +) ctx W_o + b + memory
+        if (small) {
+            TRY(lin_small(ctx, D, w.Wo, (int)M, D, D, EpiOutProj{w.bo, mem, first ? nullptr : x, x}, st));
+            hipLaunchKernelGGL(pf_layernorm_kernel, rows4, dim3(256), 0, st, x, (long)D, D, w.n2g, w.n2b, hbuf, (long)D, D, M, PF_LN_EPS);
+            LAUNCH_CHECK();
+            TRY(lin_small(hbuf, D, w.W1, (int)M, FFN, D, EpiBiasReluP{w.b1, ffn, FFN}, st));
+            TRY(lin_small(ffn, FFN, w.W2, (int)M, D, FFN, EpiBiasResP{w.b2, x, D}, st));
+            continue;
+        }
         if (launch_h3_split_rows(ctx, D, hp, hs, M, D, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
         TRY(lin3(hp, hs, w.ho, (int)M, D, D, EpiOutProj{w.bo, mem, first ? nullptr : x, x}, st));
         // ---- x += W2 relu(W1 LN(x) + b1) + b2
@@ -546,7 +573,7 @@ __global__ __launch_bounds__(256) void pf_argmax_kernel(const float* __restrict_
     if (lane == 0) { ids[m] = bi; if (score) score[m] = -logf(s); }
 }
 
-struct PfDecLayer { PfW3 h1, h2, hq, hkv, ho; const float *b1, *fg, *fb, *n1g, *n1b, *n2g, *n2b, *n3g, *n3b, *fsmnT, *bq, *bkv, *bo; };
+struct PfDecLayer { PfW3 h1, h2, hq, hkv, ho; const float *W1, *W2, *Wq, *Wkv, *Wo; const float *b1, *fg, *fb, *n1g, *n1b, *n2g, *n2b, *n3g, *n3b, *fsmnT, *bq, *bkv, *bo; };
 
 }  // namespace
 
@@ -556,7 +583,7 @@ struct tdx_pfdec {
     float* dev = nullptr; unsigned char* dev_planes = nullptr;
     std::vector<PfDecLayer> layers; PfDecLayer d3;
     PfW3 hcif, hout;
-    const float *cifb, *cifw, *cifob, *ang, *anb, *bout;
+    const float *cifb, *cifw, *cifob, *ang, *anb, *bout, *Wout;
 };
 
 extern "C" {
@@ -631,17 +658,18 @@ int tdx_pfdec_create(int num_blocks, int vocab, const void* blob, size_t blob_by
     std::vector<Job> jobs;
     auto bind_ff = [&](const Off& o, PfDecLayer& w) {
         w.b1 = dev + o.b1; w.fg = dev + o.fg; w.fb = dev + o.fb; w.n1g = dev + o.n1g; w.n1b = dev + o.n1b;
+        w.W1 = dev + o.W1; w.W2 = dev + o.W2;
         jobs.push_back({dev + o.W1, FFN, D, &w.h1}); jobs.push_back({dev + o.W2, D, FFN, &w.h2});
     };
     for (int l = 0; l < num_blocks; ++l) {
         const Off& o = offs[l]; PfDecLayer& w = h->layers[l];
         bind_ff(o, w);
         w.n2g = dev + o.n2g; w.n2b = dev + o.n2b; w.n3g = dev + o.n3g; w.n3b = dev + o.n3b; w.fsmnT = dev + o.fsmnT;
-        w.bq = dev + o.bq; w.bkv = dev + o.bkv; w.bo = dev + o.bo;
+        w.bq = dev + o.bq; w.bkv = dev + o.bkv; w.bo = dev + o.bo; w.Wq = dev + o.Wq; w.Wkv = dev + o.Wkv; w.Wo = dev + o.Wo;
         jobs.push_back({dev + o.Wq, D, D, &w.hq}); jobs.push_back({dev + o.Wkv, 2 * D, D, &w.hkv}); jobs.push_back({dev + o.Wo, D, D, &w.ho});
     }
     bind_ff(offs[num_blocks], h->d3);
-    h->cifb = dev + cifb; h->cifw = dev + cifw; h->cifob = dev + cifob; h->ang = dev + ang; h->anb = dev + anb; h->bout = dev + bout;
+    h->cifb = dev + cifb; h->cifw = dev + cifw; h->cifob = dev + cifob; h->ang = dev + ang; h->anb = dev + anb; h->bout = dev + bout; h->Wout = dev + Wout;
     jobs.push_back({dev + cifW, D, 3 * D, &h->hcif}); jobs.push_back({dev + Wout, vpad, D, &h->hout});
     size_t bytes = 0;
     for (const Job& j : jobs) bytes += (size_t)j.N * j.K * 4 + al(j.N) * 4;
@@ -700,7 +728,7 @@ int tdx_pfdec_predict(tdx_pfdec* h, const float* enc, int B, int T, float* alpha
 size_t tdx_pfdec_decode_workspace_bytes(const tdx_pfdec* h, int B, int L, int T) {
     if (!h || B < 1 || L < 1 || T < 1) return 0;
     const size_t M = (size_t)B * L, MT = (size_t)B * T, Tp = (size_t)(T + 127) / 128 * 128;
-    return (al(M * D) * 5 + al(M * FFN) * 2 + al(M) + al(MT * D) + al(MT) + al((MT + 128) * 2 * D) + al((size_t)B * H * L * Tp) + al((M + 128) * D) +
+    return (al(M * D) * 5 + al(M * FFN) * 3 + al(M) + al(MT * D) + al(MT) + al((MT + 128) * 2 * D) + al((size_t)B * H * L * Tp) + al((M + 128) * D) +
             al(M * (size_t)h->vpad)) * sizeof(float);
 }
 
@@ -726,11 +754,22 @@ int tdx_pfdec_decode(tdx_pfdec* h, const float* emb, int emb_rows, const int* co
     float* sc = kv + al((MT + 128) * 2 * D);
     float* ctx = sc + al((size_t)B * H * L * Tp);
     float* logits = ctx + al((M + 128) * D);
+    float* lnf = logits + al(M * (size_t)h->vpad);          // fp32 LayerNorm outputs of the small-row path [M][<= 2048]
     const dim3 rows4((unsigned)((M + 3) / 4));
+    const bool small = M <= PF_SMALL_ROWS, small_mem = MT <= PF_SMALL_ROWS;       // few rows: Linears on the exact-fp32 core (see lin_small)
     if (hipMemcpy2DAsync(x, (size_t)L * D * 4, emb, (size_t)emb_rows * D * 4, (size_t)L * D * 4, B, hipMemcpyDeviceToDevice, st) != hipSuccess)
         return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
     if (launch_h3_split_rows(enc, D, encP, encS, MT, D, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
     auto ffn_block = [&](const PfDecLayer& w, const float* in, float* outp) -> int {      // w_2(LN(relu(w_1(LN(in)))))
+        if (small) {
+            hipLaunchKernelGGL(pf_layernorm_kernel, rows4, dim3(256), 0, st, in, (long)D, D, w.n1g, w.n1b, lnf, (long)D, D, M, PF_LN_EPS);
+            LAUNCH_CHECK();
+            TRY(lin_small(lnf, D, w.W1, (int)M, FFN, D, EpiBiasReluP{w.b1, ffn, FFN}, st));
+            hipLaunchKernelGGL(pf_layernorm_kernel, rows4, dim3(256), 0, st, ffn, (long)FFN, FFN, w.fg, w.fb, lnf, (long)FFN, FFN, M, PF_LN_EPS);
+            LAUNCH_CHECK();
+            TRY(lin_small(lnf, FFN, w.W2, (int)M, D, FFN, EpiStoreP{outp, D}, st));
+            return TDX_OK;
+        }
         hipLaunchKernelGGL(pf_layernorm_planes_kernel_t<2>, rows4, dim3(256), 0, st, in, (long)D, D, w.n1g, w.n1b, hp, hs, D, M, PF_LN_EPS);
         LAUNCH_CHECK();
         TRY(lin3(hp, hs, w.h1, (int)M, FFN, D, EpiBiasReluP{w.b1, ffn, FFN}, st));
@@ -755,10 +794,17 @@ int tdx_pfdec_decode(tdx_pfdec* h, const float* emb, int emb_rows, const int* co
         hipLaunchKernelGGL(pf_add_masked_kernel, dim3((unsigned)((M * (D / 4) + 255) / 256)), dim3(256), 0, st, x, memt, M, L, counts);
         LAUNCH_CHECK();
         // ---- cross attention on the encoder output: x += W_o softmax(q k^T / sqrt(dk)) v + b_o
-        hipLaunchKernelGGL(pf_layernorm_planes_kernel_t<2>, rows4, dim3(256), 0, st, x, (long)D, D, w.n3g, w.n3b, hp, hs, D, M, PF_LN_EPS);
-        LAUNCH_CHECK();
-        TRY(lin3(hp, hs, w.hq, (int)M, D, D, EpiBiasP{w.bq, q, D}, st));
-        TRY(lin3(encP, encS, w.hkv, (int)MT, 2 * D, D, EpiBiasP{w.bkv, kv, 2 * D}, st));
+        if (small) {
+            hipLaunchKernelGGL(pf_layernorm_kernel, rows4, dim3(256), 0, st, x, (long)D, D, w.n3g, w.n3b, lnf, (long)D, D, M, PF_LN_EPS);
+            LAUNCH_CHECK();
+            TRY(lin_small(lnf, D, w.Wq, (int)M, D, D, EpiBiasP{w.bq, q, D}, st));
+        } else {
+            hipLaunchKernelGGL(pf_layernorm_planes_kernel_t<2>, rows4, dim3(256), 0, st, x, (long)D, D, w.n3g, w.n3b, hp, hs, D, M, PF_LN_EPS);
+            LAUNCH_CHECK();
+            TRY(lin3(hp, hs, w.hq, (int)M, D, D, EpiBiasP{w.bq, q, D}, st));
+        }
+        if (small_mem) TRY(lin_small(enc, D, w.Wkv, (int)MT, 2 * D, D, EpiBiasP{w.bkv, kv, 2 * D}, st));
+        else TRY(lin3(encP, encS, w.hkv, (int)MT, 2 * D, D, EpiBiasP{w.bkv, kv, 2 * D}, st));
         {
             GemmSeg s = make_seg(q, D, kv, 2 * D, DK, (long)L * D, (long)T * 2 * D);
             s.zdiv = H; s.strideA2 = DK; s.strideB2 = DK;
@@ -776,13 +822,20 @@ int tdx_pfdec_decode(tdx_pfdec* h, const float* emb, int emb_rows, const int* co
             if (launch_gemm<false, true, false, false>(g, B * H, EpiCtx{ctx, L}, st) != hipSuccess)
                 return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
         }
+        if (small) { TRY(lin_small(ctx, D, w.Wo, (int)M, D, D, EpiBiasResP{w.bo, x, D}, st)); continue; }
         if (launch_h3_split_rows(ctx, D, hp, hs, M, D, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
         TRY(lin3(hp, hs, w.ho, (int)M, D, D, EpiBiasResP{w.bo, x, D}, st));
     }
     TRY(ffn_block(h->d3, x, tgt));                      // decoders3: FFN only, no residual
-    hipLaunchKernelGGL(pf_layernorm_planes_kernel_t<2>, rows4, dim3(256), 0, st, tgt, (long)D, D, h->ang, h->anb, hp, hs, D, M, PF_LN_EPS);
-    LAUNCH_CHECK();
-    TRY(lin3(hp, hs, h->hout, (int)M, h->vpad, D, EpiBiasP{h->bout, logits, h->vpad}, st));
+    if (small) {
+        hipLaunchKernelGGL(pf_layernorm_kernel, rows4, dim3(256), 0, st, tgt, (long)D, D, h->ang, h->anb, lnf, (long)D, D, M, PF_LN_EPS);
+        LAUNCH_CHECK();
+        TRY(lin_small(lnf, D, h->Wout, (int)M, h->vpad, D, EpiBiasP{h->bout, logits, h->vpad}, st));
+    } else {
+        hipLaunchKernelGGL(pf_layernorm_planes_kernel_t<2>, rows4, dim3(256), 0, st, tgt, (long)D, D, h->ang, h->anb, hp, hs, D, M, PF_LN_EPS);
+        LAUNCH_CHECK();
+        TRY(lin3(hp, hs, h->hout, (int)M, h->vpad, D, EpiBiasP{h->bout, logits, h->vpad}, st));
+    }
     hipLaunchKernelGGL(pf_argmax_kernel, rows4, dim3(256), 0, st, logits, (long)h->vpad, h->vocab, ids, score, M);
     LAUNCH_CHECK();
     return TDX_OK;

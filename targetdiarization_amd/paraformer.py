@@ -13,8 +13,10 @@ from .weights import pack_blob
 
 
 class ParaformerEncoder:
-    def __init__(self, state_dict, device="cuda:0", num_blocks: int | None = None, cmvn_shift=None, cmvn_scale=None):
+    def __init__(self, state_dict, device="cuda:0", num_blocks: int | None = None, cmvn_shift=None, cmvn_scale=None, graph_rows: int = 2048):
+        """graph_rows: forwards with B*T <= graph_rows LFR frames are replayed as HIP graphs (_lib.GraphRunner); 0 disables"""
         self.device = torch.device(device)
+        self.graph_rows = graph_rows
         if self.device.type != "cuda":
             raise _lib.TdxError("ParaformerEncoder needs a HIP device")
         if num_blocks is None:
@@ -29,6 +31,7 @@ class ParaformerEncoder:
         _lib.check(self._l.tdx_pfenc_create(num_blocks, buf, len(blob), idx, C.byref(h)))
         self._h = h
         self._ws = None
+        self._graphs = _lib.GraphRunner(self.device)
         self.fbank = Fbank("asr", self.device)
         # am.mvn vectors (funasr WavFrontend.apply_cmvn): (x + shift) * scale; identity if absent
         self.cmvn_shift = (cmvn_shift if cmvn_shift is not None else torch.zeros(560)).to(self.device).float()
@@ -45,6 +48,10 @@ class ParaformerEncoder:
         feats = feats.to(self.device, torch.float32).contiguous()
         B, T, _ = feats.shape
         nb = int(self._l.tdx_pfenc_workspace_bytes(self._h, B, T))
+        if self.graph_rows and B * T <= self.graph_rows:
+            def launch(si, so, ws, st):
+                _lib.check(self._l.tdx_pfenc_forward(self._h, si.data_ptr(), None, B, T, so.data_ptr(), ws.data_ptr(), ws.numel(), st))
+            return self._graphs((B, T), feats, (B, T, 512), nb, launch)
         if self._ws is None or self._ws.numel() < nb:
             self._ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
         out = torch.empty(B, T, 512, device=self.device)

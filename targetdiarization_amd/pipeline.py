@@ -154,7 +154,7 @@ class HotPath:
 
     # ---- whole path over a shard ------------------------------------------------------------
     def run(self, utts, target_embedding=None, rank: int = 0, world: int = 1, n_total: int | None = None, with_asr: bool = True,
-            to_host: bool = True, embed_segment: int | None = None):
+            to_host: bool = True, embed_segment: int | None = None, target_clip=None):
         """utts: THIS rank's utterances (utterance i of the job lives on rank i % world), host arrays or
         device tensors.  Returns dict with the separated streams, the all-gathered embeddings [n_total*k,192]
         (utterance order), cosine scores vs `target_embedding`, and encoder outputs of the local streams.
@@ -162,9 +162,28 @@ class HotPath:
         stream into pieces of that many samples (the last piece keeps the remainder if it has >= 9 fbank frames)
         and embeds each piece — the per-window scoring of a long recording (BASELINE configs[2]/[3]); the all-gather
         then needs every utterance to produce the same number of pieces.
-        to_host=False leaves every result on the device (the benchmark's resident-in-HBM boundary)."""
+        to_host=False leaves every result on the device (the benchmark's resident-in-HBM boundary).
+        target_clip: the target speaker's sample as a waveform instead of `target_embedding` (TargetDiarization.infer has both clips
+        at hand, :98-121): its embedding is computed on a side stream WHILE the mix is separated.
+        Small inputs (the reference's one-clip-per-call pattern: every kernel is far from filling the GPU) overlap the independent
+        stages on HIP streams: target embedding || separation, then speaker embeddings || Paraformer."""
         n_total = n_total if n_total is not None else len(utts)
+        main = torch.cuda.current_stream(self.device)
+        overlap = sum(int(u.shape[0]) for u in utts) <= 60 * 16000
+        side0 = None
+        if target_clip is not None and self.spk is not None:
+            tclip = self._dev(target_clip)
+            if overlap:
+                side0 = torch.cuda.Stream(self.device)
+                side0.wait_stream(main)
+                with torch.cuda.stream(side0):
+                    target_embedding = self.spk.embed_device([tclip])[0]
+                target_embedding.record_stream(main)
+            else:
+                target_embedding = self.spk.embed_device([tclip])[0]
         sep = self.separate_device(utts)
+        if side0 is not None:
+            main.wait_stream(side0)
         out = {"streams": sep}
         flat = [p[k] for p in sep for k in (0, 1)]
         if self.spk is not None:
@@ -184,18 +203,31 @@ class HotPath:
             local = self.spk.embed_device(clips) if clips else torch.zeros(0, 192, device=self.device)
             allemb = gather_embeddings(local, n_total, rank, world, streams=per)
             out["embeddings"] = allemb
+            if target_clip is not None:
+                out["target_embedding"] = target_embedding
             if target_embedding is not None:
                 from . import ops
                 tgt = target_embedding if isinstance(target_embedding, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(target_embedding, dtype=np.float32))
                 out["scores"] = ops.cosine_scores(allemb, tgt.to(self.device, torch.float32)) if allemb.shape[0] else torch.zeros(0, device=self.device)
         if self.asr is not None and with_asr:
-            if self.dec is not None:
-                out["encoder"], out["asr"] = self.encode_device(flat, decode=True)      # tokens + timestamps per <= 30 s segment
-            else:
-                out["encoder"] = self.encode_device(flat)
+            # (issued after the embedding launches above: the decoder reads its token counts back, and that host wait then
+            # overlaps embeddings already queued on the main stream)
+            side = None
+            if overlap and world == 1:
+                side = torch.cuda.Stream(self.device)
+                side.wait_stream(main)
+            with torch.cuda.stream(side if side is not None else main):
+                if self.dec is not None:
+                    out["encoder"], out["asr"] = self.encode_device(flat, decode=True)      # tokens + timestamps per <= 30 s segment
+                else:
+                    out["encoder"] = self.encode_device(flat)
+            if side is not None:
+                for t in out["encoder"]:
+                    t.record_stream(main)
+                main.wait_stream(side)
         if to_host:                                   # the one D2H of the path
             out["streams"] = [(p[0].cpu().numpy(), p[1].cpu().numpy()) for p in sep]
-            for k in ("embeddings", "scores"):
+            for k in ("embeddings", "scores", "target_embedding"):
                 if k in out:
                     out[k] = out[k].cpu().numpy()
             if "encoder" in out:

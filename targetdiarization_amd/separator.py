@@ -16,7 +16,10 @@ from .weights import pack_blob
 
 
 class MossFormer2Separator:
-    def __init__(self, state_dict, device="cuda:0", num_blocks: int | None = None):
+    def __init__(self, state_dict, device="cuda:0", num_blocks: int | None = None, graph_rows: int = 40000):
+        """graph_rows: forwards with B*S <= graph_rows token rows (the reference's own call pattern: ONE window per call) are
+        captured once per (B, T) as a HIP graph and replayed — the ~450 launches of a forward are then one submission (at
+        S = 17 000 the kernels are 20-100 us each and the launch gaps are a tenth of the time); 0 disables."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.TdxError("MossFormer2Separator needs a HIP device (cuda:N); there is no CPU path")
@@ -34,6 +37,9 @@ class MossFormer2Separator:
         self._h = h
         self._ws = None
         self._taps = False
+        self._profiling = False
+        self.graph_rows = graph_rows
+        self._graphs = _lib.GraphRunner(self.device)
 
     @classmethod
     def from_pretrain(cls, path, device="cuda:0", **model_args):
@@ -71,6 +77,7 @@ class MossFormer2Separator:
 
     def profile_enable(self, max_records: int):
         _lib.check(self._l.tdx_mf2_profile_enable(self._h, max_records))
+        self._profiling = max_records > 0
 
     def profile_collect(self):
         """(total ms, launches) of the dominant GEMM since the last collect; sync first."""
@@ -99,11 +106,27 @@ class MossFormer2Separator:
             wav = wav.squeeze(1)
         wav = wav.to(self.device, torch.float32).contiguous()
         B, T = wav.shape
+        S = (T - 16) // 8 + 1
+        if self.graph_rows and T >= 16 and B * S <= self.graph_rows and not self._taps and not self._profiling:
+            return self._forward_graph(wav, B, T)
         ws = self._workspace(B, T)
         out = torch.empty(B, 2, T, dtype=torch.float32, device=self.device)
         st = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(self._l.tdx_mf2_forward(self._h, wav.data_ptr(), B, T, out.data_ptr(), ws.data_ptr(), ws.numel(), st))
         self._last = (B, T)
+        return out
+
+    def _forward_graph(self, wav, B, T):
+        """small forwards: HIP-graph replay (_lib.GraphRunner)"""
+        need = self.workspace_bytes(B, T)
+        if need == 0:
+            raise _lib.TdxError(f"bad shape B={B} T={T}")
+
+        def launch(si, so, ws, st):
+            _lib.check(self._l.tdx_mf2_forward(self._h, si.data_ptr(), B, T, so.data_ptr(), ws.data_ptr(), ws.numel(), st))
+        out = self._graphs((B, T), wav, (B, 2, T), need, launch)
+        self._last = (B, T)
+        self._ws = self._graphs._g[(B, T)][3]
         return out
 
     forward = __call__

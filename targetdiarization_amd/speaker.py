@@ -13,8 +13,10 @@ from .weights import pack_blob
 
 
 class ERes2NetV2:
-    def __init__(self, state_dict, device="cuda:0"):
+    def __init__(self, state_dict, device="cuda:0", graph_frames: int = 4000):
+        """graph_frames: forwards with B*F <= graph_frames fbank frames are replayed as HIP graphs (_lib.GraphRunner); 0 disables"""
         self.device = torch.device(device)
+        self.graph_frames = graph_frames
         if self.device.type != "cuda":
             raise _lib.TdxError("ERes2NetV2 needs a HIP device")
         self._l = _lib.lib()
@@ -27,6 +29,7 @@ class ERes2NetV2:
             _lib.check(self._l.tdx_eres2net_create(buf, len(blob), idx, C.byref(h)))
         self._h = h
         self._ws = None
+        self._graphs = _lib.GraphRunner(self.device)
         self.fbank = Fbank("sv", self.device)
 
     def flops(self, B, F):
@@ -39,6 +42,11 @@ class ERes2NetV2:
         nb = int(self._l.tdx_eres2net_workspace_bytes(self._h, B, F))
         if nb == 0:
             raise _lib.TdxError("ERes2NetV2: need at least 9 fbank frames")
+        if self.graph_frames and B * F <= self.graph_frames:
+            def launch(si, so, ws, st):
+                _lib.check(self._l.tdx_eres2net_forward(self._h, si.data_ptr(), B, F, so.data_ptr(), ws.data_ptr(), ws.numel(), st))
+            with torch.cuda.device(self.device):
+                return self._graphs((B, F), feat, (B, 192), nb, launch)
         if self._ws is None or self._ws.numel() < nb:
             self._ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
         out = torch.empty(B, 192, device=self.device)

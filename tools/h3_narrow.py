@@ -19,16 +19,20 @@ for (m, n, k) in shapes:
     c0 = torch.empty(m, n, device=dev); c1 = torch.empty(m, n, device=dev)
     assert gv(pa.data_ptr(), sa.data_ptr(), pb.data_ptr(), sb.data_ptr(), bias.data_ptr(), c0.data_ptr(), m, n, k, 0, None) == 0
     assert gv(pa.data_ptr(), sa.data_ptr(), pb.data_ptr(), sb.data_ptr(), bias.data_ptr(), c1.data_ptr(), m, n, k, 10, None) == 0
+    c2 = torch.empty(m, n, device=dev)
+    assert gv(pa.data_ptr(), sa.data_ptr(), pb.data_ptr(), sb.data_ptr(), bias.data_ptr(), c2.data_ptr(), m, n, k, 20, None) == 0
     torch.cuda.synchronize()
     mm = min(m, 4096)
     ref = a[:mm].double() @ w.double().T + bias.double()
     e_w = float((c0[:mm].double() - ref).norm() / ref.norm()); e_n = float((c1[:mm].double() - ref).norm() / ref.norm())
-    print(f"M={m} N={n} K={k}: wide vs fp64 {e_w:.2e}, narrow vs fp64 {e_n:.2e}, narrow == wide: {bool(torch.equal(c0, c1))}", flush=True)
-    del c0, c1, ref
+    e_p = float((c2[:mm].double() - ref).norm() / ref.norm())
+    print(f"M={m} N={n} K={k}: wide vs fp64 {e_w:.2e}, narrow vs fp64 {e_n:.2e}, narrow == wide: {bool(torch.equal(c0, c1))}, pair-stage vs fp64 {e_p:.2e}, "
+          f"pair-stage vs wide (all rows) {float((c2.double() - c0.double()).norm() / c0.double().norm()):.2e}", flush=True)
+    del c0, c1, c2, ref
     for label in ("random", "zeros"):
         if label == "zeros":
             pa.zero_(); pb.zero_()
-        for v in (0, 6, 10, 16):
+        for v in (0, 6, 20, 10):
             for _ in range(2):
                 gv(pa.data_ptr(), sa.data_ptr(), pb.data_ptr(), sb.data_ptr(), bias.data_ptr(), c.data_ptr(), m, n, k, v, None)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -288,11 +288,13 @@ def pipe_bench(args):
         ach = gemm_flops_total / (gemm_ms * 1e-3) / 1e12 if gemm_launches else None
         full_rows = min(args.windows_per_launch, n_win_rank) * S
         traffic = None
+        mfma_util = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             tj = json.load(open(tf))
             bpr = tj.get("gemm_to_hidden_hbm_bytes_per_token_row")
             traffic = bpr * full_rows if bpr else None
+            mfma_util = tj.get("mfma_pipe_utilisation")
         line = {
             "metric": METRIC, "value": value, "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if wl == "cfg5" else "weak",
@@ -306,6 +308,8 @@ def pipe_bench(args):
                          "launches_timed": gemm_launches, "ms_per_launch": gemm_ms / max(gemm_launches, 1),
                          "algorithmic_flops_per_launch": 2.0 * full_rows * 512 * 2176,
                          "token_rows_per_full_launch": full_rows,
+                         "mfma_pipe_utilisation_pmc": mfma_util,      # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x busy cycles), profiles/r02_e_pmc_sq.json
+                         "traffic_note": "HBM-side bytes per full launch = (FETCH_SIZE x2 + WRITE_SIZE) per token row from the PMC passes in profiles/traffic.json x rows",
                          "whole_path_tflops_per_gpu": sum(fl.values()) * args.steps / dt / 1e12,
                          "whole_path_frac": sum(fl.values()) * args.steps / dt / 1e12 / PEAK_H3_TFLOPS},
             "stage_ms_per_step_rank0": stage_ms,

@@ -42,7 +42,7 @@ class TargetDiarization:
                  cuda_device: int = 0, verbose_log: bool = False, *args,
                  sep_state_dict=None, spk_state_dict=None, asr_state_dict=None,
                  sd_pipeline: Optional[Callable] = None, od_pipeline: Optional[Callable] = None,
-                 vad: Optional[Callable] = None, decoder: Optional[Callable] = None, **kwargs):
+                 vad: Optional[Callable] = None, decoder: Optional[Callable] = None, mdx_model: Optional[Callable] = None, token_list=None, **kwargs):
         self.target_similarity_threshold = target_similarity_threshold
         self.asr_engine = asr_engine
         self.cuda_device = cuda_device
@@ -51,7 +51,9 @@ class TargetDiarization:
         self.od_pipeline = od_pipeline
         self.vad = vad or _whole_clip_vad
         self.decoder = decoder
-        self.hp = HotPath(sep_state_dict, spk_state_dict, asr_state_dict, cuda_device=cuda_device)
+        self.token_list = token_list          # funasr's tokens.json (absent here): ids -> text; None -> "<id>" placeholders
+        self.hp = HotPath(sep_state_dict, spk_state_dict, asr_state_dict, cuda_device=cuda_device, mdx_model=mdx_model,
+                          mdx_weights_file=mdx_weights_file)
 
     # ---- small DSP helpers kept from AudioProcessor ------------------------------------------
     @staticmethod
@@ -68,14 +70,29 @@ class TargetDiarization:
             return audio
         return (audio * (10.0 ** ((target_loudness - loud) / 20.0))).astype(np.float32)
 
-    def audio_preprocess(self, audio):
-        """:166-182 minus resample/denoise: mono float32 at -23 LUFS"""
+    def audio_preprocess(self, audio, sampling_rate: int = 16000, stream_mode: bool = False):
+        """:166-182: mono -> float32 -> 16 kHz -> -23 LUFS -> denoise_vocal (or, in stream mode, the louder separated stream) ->
+        -23 LUFS again; a failure inside the chain is printed and the audio of the last good step returned, like the reference"""
         audio = np.asarray(audio)
         if audio.ndim > 1:
             audio = audio.mean(axis=-1)
         if audio.dtype == np.int16:
             audio = audio.astype(np.float32) / 32768.0
-        return self.audio_loudness_control(audio.astype(np.float32))
+        audio = audio.astype(np.float32)
+        try:
+            if sampling_rate != 16000:
+                audio, sampling_rate = self.hp.ap.audio_resample(audio, sampling_rate, 16000)
+            audio = self.audio_loudness_control(audio)
+            if stream_mode:
+                audio, _ = self.hp.ap.separate_speaker(audio, sampling_rate)
+            elif self.hp.ap.is_denoise_vocal:
+                audio = self.hp.ap.denoise_vocal(audio, sampling_rate)[: audio.shape[0]]
+            else:
+                return audio              # (denoiser off: the reference's fast_mode falls back to noisereduce, a third-party CPU package)
+            audio = self.audio_loudness_control(audio)
+        except Exception as e:
+            print(f"Failed in func audio_preprocess: {e}")
+        return audio
 
     # ---- segmentation parsers ----------------------------------------------------------------
     def od_result_parser(self, od_result, sd_result={}, is_single=False, output_overlap=True):
@@ -189,16 +206,27 @@ class TargetDiarization:
         out = []
         spks = list(dict.fromkeys(it["speaker"] for it in items))
         timelines = [self.combine_audio_chunks(items, spk) for spk in spks]
-        encs = self.hp.encode_streams([t for t in timelines if t is not None]) if self.hp.asr is not None else []
+        lines = [t for t in timelines if t is not None]
+        encs, dres = [], None
+        if self.hp.asr is not None and lines:
+            if self.decoder is None and self.hp.dec is not None:       # the device CIF + NAR decoder (N2)
+                encs, dres = self.hp.encode_device(lines, decode=True)
+            else:
+                encs = self.hp.encode_streams(lines)
         k = 0
         for spk, tl in zip(spks, timelines):
             if tl is None:
                 continue
             text, stamps = ("", [])
             if self.hp.asr is not None:
-                enc = encs[k]; k += 1
-                if self.decoder is not None:
+                enc = encs[k]
+                if dres is not None:
+                    tok = lambda i: self.token_list[i] if self.token_list is not None and i < len(self.token_list) else f"<{i}>"
+                    stamps = [(tok(i), [round(a / 1000.0, 3), round(b / 1000.0, 3)]) for seg in dres[k] for i, (a, b) in zip(seg["token_ids"], seg["timestamp"])]
+                    text = "".join(t for t, _ in stamps)
+                elif self.decoder is not None:
                     text, stamps = self.decoder(enc)
+                k += 1
             for it in items:
                 if it["speaker"] != spk:
                     continue

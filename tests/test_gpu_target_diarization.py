@@ -83,3 +83,25 @@ def test_target_asr_and_asr_processor_mirrors(gold):
     assert seen["shape"] == ((frames + 5) // 6, 512)
     assert res[0]["timestamp"] == [("a", [0.0, 0.5]), ("b", [0.5, 0.9])] and res[0]["language"] == "en" and res[0]["key"] == "clip_0"
     assert ap.asr_detection(tgt, output_text_only=True) == "a b"
+
+
+def test_infer_with_device_decoder_and_denoiser(gold, sd2):
+    """the full chain of infer(): audio_preprocess (loudness -> denoise_vocal with an identity MDX body -> loudness, :166-182), separation
+    of the overlap, target selection, and the ASR forward down to tokens through the device CIF + NAR decoder (N2)"""
+    from targetdiarization_amd.target_diarization import TargetDiarization
+    from targetdiarization_amd.weights import (recipe_eres2netv2_state_dict, recipe_paraformer_decoder_state_dict,
+                                               recipe_paraformer_state_dict)
+    mix, tgt = _load(gold, "chat_mix.wav"), _load(gold, "female_a.wav")
+    asr_sd = dict(recipe_paraformer_state_dict(0, 2)); asr_sd.update(recipe_paraformer_decoder_state_dict(0, 2))
+    sd_rows = {"text": [[0.0, 3.0, 0], [2.4, 5.5, 1], [5.5, 8.6, 0]]}
+    od = [(0.0, 3.0, "SPEAKER_00"), (2.4, 5.5, "SPEAKER_01"), (5.5, 8.6, "SPEAKER_00")]
+    td = TargetDiarization(cuda_device=0, sep_state_dict=sd2, spk_state_dict=recipe_eres2netv2_state_dict(0), asr_state_dict=asr_sd,
+                           sd_pipeline=lambda a: sd_rows, od_pipeline=lambda a: od, mdx_model=lambda spec: spec,
+                           mdx_weights_file="mdx/weights/Kim_Vocal_2.onnx", token_list=[f"w{i}|" for i in range(8404)])
+    assert td.hp.ap.is_denoise_vocal and td.hp.dec is not None
+    pre = td.audio_preprocess(mix)
+    assert pre.shape == mix.shape and pre.dtype == np.float32 and np.isfinite(pre).all()
+    spk, res, aud = td.infer(mix, tgt)
+    assert spk in ("0", "1") and res
+    texts = [r["text"] for r in res]
+    assert any(t for t in texts) and all(t == "" or t.startswith("w") for t in texts)      # recipe weights: arbitrary tokens, but tokens

@@ -127,6 +127,10 @@ __global__ __launch_bounds__(256) void pf_softmax_kernel(float* __restrict__ sc,
     for (int c = lane; c < Sp; c += 64) row[c] = c < S ? row[c] * inv : 0.f;
 }
 
+struct EpiStoreZ { float* out; long ld; long strideZ;       // plain store per batch (split-K slabs)
+    __device__ EpiNone col(int, int) const { return EpiNone{}; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ void store(int z, int m, int n, float v, EpiNone, EpiNone) const { out[(long)z * strideZ + (long)m * (int)ld + n] = v; } };
 struct EpiBiasP { const float* b; float* out; long ld;
     __device__ float col(int, int n) const { return b[n]; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
@@ -178,15 +182,54 @@ int lin3(const unsigned char* Ap, const float* As, const PfW3& W, int M, int N, 
     return TDX_OK;
 }
 
-// the same Linear on the exact-fp32 MFMA core (gemm.hpp: 128x128x32 tiles, 3 blocks per CU), meant for SMALL row counts (one clip per
-// call has a few hundred rows; a single x3 tile then walks its whole K loop alone, K = 2048: 128 stages ~ 190 us).  MEASURED at
-// config 1 (2 x 145 LFR frames): SLOWER than the x3 path (50-layer encoder 24.4 vs 18.8 ms, decoder 7.8 vs 5.6 ms) — the fp32 core's
-// 64 k-steps of K = 2048 are no shorter.  Kept switchable for the record; 0 = off.  A fp32 [M][lda], W fp32 [N][K].
-constexpr long PF_SMALL_ROWS = 0;
-template <class Epi>
-int lin_small(const float* A, long lda, const float* W, int M, int N, int K, Epi e, hipStream_t st) {
-    GemmArgs g = make_args(M, N, make_seg(A, lda, W, K, K));
-    if (launch_gemm<false, false, false, false>(g, 1, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+// SPLIT-K for small row counts.  One clip per call (the reference's call pattern) has a few hundred rows: one or two x3 tiles
+// per Linear, each walking its whole K loop alone (K = 2048: 128 stages ~ 190 us, most CUs idle).  The K range is cut into
+// chunks that run as the BATCHES of one launch (A/B pointers advance by the chunk's bytes per batch, same scales) into an fp32
+// slab [nsplit][M][N]; a small kernel sums the slab and applies the Linear's epilogue.  (Tried before: the exact-fp32 core for
+// these shapes — slower, 24.4 vs 18.8 ms for the 50-layer encoder at 2 x 145 frames.)
+constexpr long PF_SPLITK_ROWS = 512;
+constexpr size_t PF_SLAB = (size_t)PF_SPLITK_ROWS * 4096;          // floats: max over the Linears of nsplit * M * N
+enum { RK_BIAS = 0, RK_BIAS_RELU = 1, RK_BIAS_RES = 2, RK_OUTPROJ = 3, RK_STORE = 4 };
+template <int MODE>
+__global__ __launch_bounds__(256) void pf_splitk_reduce_kernel(const float* __restrict__ slab, int nsplit, long M, int N, const float* __restrict__ bias,
+                                                                float* __restrict__ out, long ldo, const float* __restrict__ mem, const float* __restrict__ resid) {
+    const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i4 >= M * (N / 4)) return;
+    const long m = i4 / (N / 4);
+    const int n = (int)(i4 - m * (N / 4)) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < nsplit; ++z) {
+        const float4 p = *reinterpret_cast<const float4*>(slab + ((long)z * M + m) * N + n);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    if (MODE != RK_STORE) { const float4 b = *reinterpret_cast<const float4*>(bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+    if (MODE == RK_BIAS_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    float4* o = reinterpret_cast<float4*>(out + m * ldo + n);
+    if (MODE == RK_BIAS_RES) { const float4 x = *o; v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w; }
+    if (MODE == RK_OUTPROJ) {
+        float4 a = *reinterpret_cast<const float4*>(mem + m * D + n);
+        if (resid) { const float4 r = *reinterpret_cast<const float4*>(resid + m * D + n); a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w; }
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    *o = v;
+}
+inline int pf_nsplit(long M, int K) {          // chunks of >= 256 k (a multiple of 32), at most 8
+    if (M > PF_SPLITK_ROWS || K < 512) return 1;
+    int ns = K / 256; if (ns > 8) ns = 8;
+    while (ns > 1 && (K % ns || (K / ns) % 32)) --ns;
+    return ns;
+}
+template <int MODE>
+int lin3_splitk(const unsigned char* Ap, const float* As, const PfW3& W, int M, int N, int K, int nsplit, float* slab, const float* bias, float* out,
+                long ldo, const float* mem, const float* resid, hipStream_t st) {
+    const int Kc = K / nsplit;
+    H3Args g{};
+    g.seg[0] = h3_seg(Ap, As, 4L * K, W.p, W.s, 4L * K, Kc);
+    g.seg[0].strideA = 4L * Kc; g.seg[0].strideB = 4L * Kc;           // batch z = K chunk z: the planes pointers advance by the chunk
+    g.nseg = 1; g.M = M; g.N = N;
+    if (launch_gemm_h3<false>(g, nsplit, EpiStoreZ{slab, (long)N, (long)M * N}, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    hipLaunchKernelGGL((pf_splitk_reduce_kernel<MODE>), dim3((unsigned)(((long)M * (N / 4) + 255) / 256)), dim3(256), 0, st, slab, nsplit, (long)M, N, bias, out, ldo, mem, resid);
+    LAUNCH_CHECK();
     return TDX_OK;
 }
 
@@ -294,7 +337,7 @@ size_t tdx_pfenc_workspace_bytes(const tdx_pfenc* h, int B, int T) {
     if (!h || B < 1 || T < 1) return 0;
     const size_t M = (size_t)B * T, Sp = (size_t)(T + 127) / 128 * 128;
     return (al(M * D) + al(M * DINP) + al(M * DINP) + al((M + 128) * 3 * D) + al((size_t)B * H * Sp * Sp) + al(M * D) + al(M * D) +
-            al(M * FFN) + al(M * FFN) + al(M)) * sizeof(float);      // + planes of the current GEMM's A operand (<= 2048 wide) and its row scales
+            al(M * FFN) + al(M * FFN) + al(M) + PF_SLAB) * sizeof(float);      // + planes of the current GEMM's A operand (<= 2048 wide), its row scales, split-K slab
 }
 
 double tdx_pfenc_flops(const tdx_pfenc* h, int B, int T) {
@@ -323,7 +366,7 @@ int tdx_pfenc_forward(tdx_pfenc* h, const float* feats, const int* lens_host, in
     unsigned char* hp = (unsigned char*)(ffn + al(M * FFN));
     float* hs = (float*)hp + al(M * FFN);
     const dim3 rows4((unsigned)((M + 3) / 4));
-    const bool small = M <= PF_SMALL_ROWS;          // few rows: Linears on the exact-fp32 core (see lin_small)
+    float* slab = hs + al(M);                       // split-K partial sums of the small-row path
 
     hipLaunchKernelGGL(pf_embed_kernel, dim3(T, B), dim3(256), 0, st, feats, xin, T);
     LAUNCH_CHECK();
@@ -334,15 +377,12 @@ int tdx_pfenc_forward(tdx_pfenc* h, const float* feats, const int* lens_host, in
         const long ldx = first ? DINP : D;
         const int din = first ? DIN : D, dinp = first ? DINP : D;
         // ---- x̂ = LN(x) ; [q|k|v] = x̂ W^T + b
-        if (small) {
-            hipLaunchKernelGGL(pf_layernorm_kernel, rows4, dim3(256), 0, st, xl, ldx, din, w.n1g, w.n1b, hbuf, (long)dinp, dinp, M, PF_LN_EPS);
-            LAUNCH_CHECK();
-            TRY(lin_small(hbuf, dinp, w.Wqkv, (int)M, 3 * D, dinp, EpiBiasP{w.bqkv, qkv, 3 * D}, st));
-        } else {
-            hipLaunchKernelGGL(pf_layernorm_planes_kernel, rows4, dim3(256), 0, st, xl, ldx, din, w.n1g, w.n1b, hp, hs, dinp, M, PF_LN_EPS);
-            LAUNCH_CHECK();
+        hipLaunchKernelGGL(pf_layernorm_planes_kernel, rows4, dim3(256), 0, st, xl, ldx, din, w.n1g, w.n1b, hp, hs, dinp, M, PF_LN_EPS);
+        LAUNCH_CHECK();
+        if (const int ns = pf_nsplit(M, dinp); ns > 1)
+            TRY(lin3_splitk<RK_BIAS>(hp, hs, w.hqkv, (int)M, 3 * D, dinp, ns, slab, w.bqkv, qkv, 3 * D, nullptr, nullptr, st));
+        else
             TRY(lin3(hp, hs, w.hqkv, (int)M, 3 * D, dinp, EpiBiasP{w.bqkv, qkv, 3 * D}, st));
-        }
         // ---- FSMN memory: v + dwconv11(v)
         {
             Conv17Args a{};
@@ -372,22 +412,18 @@ int tdx_pfenc_forward(tdx_pfenc* h, const float* feats, const int* lens_host, in
                 return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
         }
         // ---- x = (residual +) ctx W_o + b + memory
-        if (small) {
-            TRY(lin_small(ctx, D, w.Wo, (int)M, D, D, EpiOutProj{w.bo, mem, first ? nullptr : x, x}, st));
-            hipLaunchKernelGGL(pf_layernorm_kernel, rows4, dim3(256), 0, st, x, (long)D, D, w.n2g, w.n2b, hbuf, (long)D, D, M, PF_LN_EPS);
-            LAUNCH_CHECK();
-            TRY(lin_small(hbuf, D, w.W1, (int)M, FFN, D, EpiBiasReluP{w.b1, ffn, FFN}, st));
-            TRY(lin_small(ffn, FFN, w.W2, (int)M, D, FFN, EpiBiasResP{w.b2, x, D}, st));
-            continue;
-        }
         if (launch_h3_split_rows(ctx, D, hp, hs, M, D, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
-        TRY(lin3(hp, hs, w.ho, (int)M, D, D, EpiOutProj{w.bo, mem, first ? nullptr : x, x}, st));
+        const int ns512 = pf_nsplit(M, D), ns2048 = pf_nsplit(M, FFN);
+        if (ns512 > 1) TRY(lin3_splitk<RK_OUTPROJ>(hp, hs, w.ho, (int)M, D, D, ns512, slab, w.bo, x, D, mem, first ? nullptr : x, st));
+        else TRY(lin3(hp, hs, w.ho, (int)M, D, D, EpiOutProj{w.bo, mem, first ? nullptr : x, x}, st));
         // ---- x += W2 relu(W1 LN(x) + b1) + b2
         hipLaunchKernelGGL(pf_layernorm_planes_kernel, rows4, dim3(256), 0, st, x, (long)D, D, w.n2g, w.n2b, hp, hs, D, M, PF_LN_EPS);
         LAUNCH_CHECK();
-        TRY(lin3(hp, hs, w.h1, (int)M, FFN, D, EpiBiasReluP{w.b1, ffn, FFN}, st));
+        if (ns512 > 1) TRY(lin3_splitk<RK_BIAS_RELU>(hp, hs, w.h1, (int)M, FFN, D, ns512, slab, w.b1, ffn, FFN, nullptr, nullptr, st));
+        else TRY(lin3(hp, hs, w.h1, (int)M, FFN, D, EpiBiasReluP{w.b1, ffn, FFN}, st));
         if (launch_h3_split_rows(ffn, FFN, hp, hs, M, FFN, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
-        TRY(lin3(hp, hs, w.h2, (int)M, D, FFN, EpiBiasResP{w.b2, x, D}, st));
+        if (ns2048 > 1) TRY(lin3_splitk<RK_BIAS_RES>(hp, hs, w.h2, (int)M, D, FFN, ns2048, slab, w.b2, x, D, nullptr, nullptr, st));
+        else TRY(lin3(hp, hs, w.h2, (int)M, D, FFN, EpiBiasResP{w.b2, x, D}, st));
     }
     hipLaunchKernelGGL(pf_layernorm_kernel, rows4, dim3(256), 0, st, x, (long)D, D, h->ang, h->anb, out, (long)D, D, M, PF_LN_EPS);
     LAUNCH_CHECK();
@@ -728,8 +764,8 @@ int tdx_pfdec_predict(tdx_pfdec* h, const float* enc, int B, int T, float* alpha
 size_t tdx_pfdec_decode_workspace_bytes(const tdx_pfdec* h, int B, int L, int T) {
     if (!h || B < 1 || L < 1 || T < 1) return 0;
     const size_t M = (size_t)B * L, MT = (size_t)B * T, Tp = (size_t)(T + 127) / 128 * 128;
-    return (al(M * D) * 5 + al(M * FFN) * 3 + al(M) + al(MT * D) + al(MT) + al((MT + 128) * 2 * D) + al((size_t)B * H * L * Tp) + al((M + 128) * D) +
-            al(M * (size_t)h->vpad)) * sizeof(float);
+    return (al(M * D) * 5 + al(M * FFN) * 2 + al(M) + al(MT * D) + al(MT) + al((MT + 128) * 2 * D) + al((size_t)B * H * L * Tp) + al((M + 128) * D) +
+            al(M * (size_t)h->vpad) + PF_SLAB) * sizeof(float);
 }
 
 // emb_dev: [B][emb_rows][512] (the predictor's output, emb_rows = T+1; the first L rows of each utterance are used),
@@ -754,28 +790,21 @@ int tdx_pfdec_decode(tdx_pfdec* h, const float* emb, int emb_rows, const int* co
     float* sc = kv + al((MT + 128) * 2 * D);
     float* ctx = sc + al((size_t)B * H * L * Tp);
     float* logits = ctx + al((M + 128) * D);
-    float* lnf = logits + al(M * (size_t)h->vpad);          // fp32 LayerNorm outputs of the small-row path [M][<= 2048]
+    float* slab = logits + al(M * (size_t)h->vpad);         // split-K partial sums of the small-row path
     const dim3 rows4((unsigned)((M + 3) / 4));
-    const bool small = M <= PF_SMALL_ROWS, small_mem = MT <= PF_SMALL_ROWS;       // few rows: Linears on the exact-fp32 core (see lin_small)
+    const int ns512 = pf_nsplit(M, D), ns2048 = pf_nsplit(M, FFN), nsT = pf_nsplit(MT, D);
     if (hipMemcpy2DAsync(x, (size_t)L * D * 4, emb, (size_t)emb_rows * D * 4, (size_t)L * D * 4, B, hipMemcpyDeviceToDevice, st) != hipSuccess)
         return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
     if (launch_h3_split_rows(enc, D, encP, encS, MT, D, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
     auto ffn_block = [&](const PfDecLayer& w, const float* in, float* outp) -> int {      // w_2(LN(relu(w_1(LN(in)))))
-        if (small) {
-            hipLaunchKernelGGL(pf_layernorm_kernel, rows4, dim3(256), 0, st, in, (long)D, D, w.n1g, w.n1b, lnf, (long)D, D, M, PF_LN_EPS);
-            LAUNCH_CHECK();
-            TRY(lin_small(lnf, D, w.W1, (int)M, FFN, D, EpiBiasReluP{w.b1, ffn, FFN}, st));
-            hipLaunchKernelGGL(pf_layernorm_kernel, rows4, dim3(256), 0, st, ffn, (long)FFN, FFN, w.fg, w.fb, lnf, (long)FFN, FFN, M, PF_LN_EPS);
-            LAUNCH_CHECK();
-            TRY(lin_small(lnf, FFN, w.W2, (int)M, D, FFN, EpiStoreP{outp, D}, st));
-            return TDX_OK;
-        }
         hipLaunchKernelGGL(pf_layernorm_planes_kernel_t<2>, rows4, dim3(256), 0, st, in, (long)D, D, w.n1g, w.n1b, hp, hs, D, M, PF_LN_EPS);
         LAUNCH_CHECK();
-        TRY(lin3(hp, hs, w.h1, (int)M, FFN, D, EpiBiasReluP{w.b1, ffn, FFN}, st));
+        if (ns512 > 1) TRY(lin3_splitk<RK_BIAS_RELU>(hp, hs, w.h1, (int)M, FFN, D, ns512, slab, w.b1, ffn, FFN, nullptr, nullptr, st));
+        else TRY(lin3(hp, hs, w.h1, (int)M, FFN, D, EpiBiasReluP{w.b1, ffn, FFN}, st));
         hipLaunchKernelGGL(pf_layernorm_planes_kernel_t<4>, rows4, dim3(256), 0, st, ffn, (long)FFN, FFN, w.fg, w.fb, hp, hs, FFN, M, PF_LN_EPS);
         LAUNCH_CHECK();
-        TRY(lin3(hp, hs, w.h2, (int)M, D, FFN, EpiStoreP{outp, D}, st));
+        if (ns2048 > 1) TRY(lin3_splitk<RK_STORE>(hp, hs, w.h2, (int)M, D, FFN, ns2048, slab, nullptr, outp, D, nullptr, nullptr, st));
+        else TRY(lin3(hp, hs, w.h2, (int)M, D, FFN, EpiStoreP{outp, D}, st));
         return TDX_OK;
     };
     for (int l = 0; l < h->L; ++l) {
@@ -794,16 +823,11 @@ int tdx_pfdec_decode(tdx_pfdec* h, const float* emb, int emb_rows, const int* co
         hipLaunchKernelGGL(pf_add_masked_kernel, dim3((unsigned)((M * (D / 4) + 255) / 256)), dim3(256), 0, st, x, memt, M, L, counts);
         LAUNCH_CHECK();
         // ---- cross attention on the encoder output: x += W_o softmax(q k^T / sqrt(dk)) v + b_o
-        if (small) {
-            hipLaunchKernelGGL(pf_layernorm_kernel, rows4, dim3(256), 0, st, x, (long)D, D, w.n3g, w.n3b, lnf, (long)D, D, M, PF_LN_EPS);
-            LAUNCH_CHECK();
-            TRY(lin_small(lnf, D, w.Wq, (int)M, D, D, EpiBiasP{w.bq, q, D}, st));
-        } else {
-            hipLaunchKernelGGL(pf_layernorm_planes_kernel_t<2>, rows4, dim3(256), 0, st, x, (long)D, D, w.n3g, w.n3b, hp, hs, D, M, PF_LN_EPS);
-            LAUNCH_CHECK();
-            TRY(lin3(hp, hs, w.hq, (int)M, D, D, EpiBiasP{w.bq, q, D}, st));
-        }
-        if (small_mem) TRY(lin_small(enc, D, w.Wkv, (int)MT, 2 * D, D, EpiBiasP{w.bkv, kv, 2 * D}, st));
+        hipLaunchKernelGGL(pf_layernorm_planes_kernel_t<2>, rows4, dim3(256), 0, st, x, (long)D, D, w.n3g, w.n3b, hp, hs, D, M, PF_LN_EPS);
+        LAUNCH_CHECK();
+        if (ns512 > 1) TRY(lin3_splitk<RK_BIAS>(hp, hs, w.hq, (int)M, D, D, ns512, slab, w.bq, q, D, nullptr, nullptr, st));
+        else TRY(lin3(hp, hs, w.hq, (int)M, D, D, EpiBiasP{w.bq, q, D}, st));
+        if (nsT > 1) TRY(lin3_splitk<RK_BIAS>(encP, encS, w.hkv, (int)MT, 2 * D, D, nsT, slab, w.bkv, kv, 2 * D, nullptr, nullptr, st));
         else TRY(lin3(encP, encS, w.hkv, (int)MT, 2 * D, D, EpiBiasP{w.bkv, kv, 2 * D}, st));
         {
             GemmSeg s = make_seg(q, D, kv, 2 * D, DK, (long)L * D, (long)T * 2 * D);
@@ -822,20 +846,14 @@ int tdx_pfdec_decode(tdx_pfdec* h, const float* emb, int emb_rows, const int* co
             if (launch_gemm<false, true, false, false>(g, B * H, EpiCtx{ctx, L}, st) != hipSuccess)
                 return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
         }
-        if (small) { TRY(lin_small(ctx, D, w.Wo, (int)M, D, D, EpiBiasResP{w.bo, x, D}, st)); continue; }
         if (launch_h3_split_rows(ctx, D, hp, hs, M, D, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
-        TRY(lin3(hp, hs, w.ho, (int)M, D, D, EpiBiasResP{w.bo, x, D}, st));
+        if (ns512 > 1) TRY(lin3_splitk<RK_BIAS_RES>(hp, hs, w.ho, (int)M, D, D, ns512, slab, w.bo, x, D, nullptr, nullptr, st));
+        else TRY(lin3(hp, hs, w.ho, (int)M, D, D, EpiBiasResP{w.bo, x, D}, st));
     }
     TRY(ffn_block(h->d3, x, tgt));                      // decoders3: FFN only, no residual
-    if (small) {
-        hipLaunchKernelGGL(pf_layernorm_kernel, rows4, dim3(256), 0, st, tgt, (long)D, D, h->ang, h->anb, lnf, (long)D, D, M, PF_LN_EPS);
-        LAUNCH_CHECK();
-        TRY(lin_small(lnf, D, h->Wout, (int)M, h->vpad, D, EpiBiasP{h->bout, logits, h->vpad}, st));
-    } else {
-        hipLaunchKernelGGL(pf_layernorm_planes_kernel_t<2>, rows4, dim3(256), 0, st, tgt, (long)D, D, h->ang, h->anb, hp, hs, D, M, PF_LN_EPS);
-        LAUNCH_CHECK();
-        TRY(lin3(hp, hs, h->hout, (int)M, h->vpad, D, EpiBiasP{h->bout, logits, h->vpad}, st));
-    }
+    hipLaunchKernelGGL(pf_layernorm_planes_kernel_t<2>, rows4, dim3(256), 0, st, tgt, (long)D, D, h->ang, h->anb, hp, hs, D, M, PF_LN_EPS);
+    LAUNCH_CHECK();
+    TRY(lin3(hp, hs, h->hout, (int)M, h->vpad, D, EpiBiasP{h->bout, logits, h->vpad}, st));
     hipLaunchKernelGGL(pf_argmax_kernel, rows4, dim3(256), 0, st, logits, (long)h->vpad, h->vocab, ids, score, M);
     LAUNCH_CHECK();
     return TDX_OK;

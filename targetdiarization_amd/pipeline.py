@@ -183,6 +183,8 @@ class HotPath:
             else:
                 target_embedding = self.spk.embed_device([tclip])[0]
         sep = self.separate_device(utts)
+        sep_done = torch.cuda.Event()
+        sep_done.record(main)                  # what the ASR side stream waits for (NOT the embedding launches queued after it)
         if side0 is not None:
             main.wait_stream(side0)
         out = {"streams": sep}
@@ -216,7 +218,7 @@ class HotPath:
             side = None
             if overlap and world == 1:
                 side = torch.cuda.Stream(self.device)
-                side.wait_stream(main)
+                side.wait_event(sep_done)
             with torch.cuda.stream(side if side is not None else main):
                 if self.dec is not None:
                     out["encoder"], out["asr"] = self.encode_device(flat, decode=True)      # tokens + timestamps per <= 30 s segment

@@ -117,7 +117,14 @@ class SpeakerEmbedder:
             for c in range(0, len(idxs), step):
                 chunk = idxs[c:c + step]
                 x = torch.stack([wavs[i] for i in chunk]).to(self.device, torch.float32)
-                out[chunk] = self.model(x)
+                y = self.model(x)
+                # (no `out[list] = y`: an index list is uploaded with a pageable H2D copy, which blocks the HOST until the stream
+                # has drained — the launches queued behind it then start late and nothing overlaps)
+                if chunk == list(range(chunk[0], chunk[0] + len(chunk))):
+                    out[chunk[0]:chunk[0] + len(chunk)] = y
+                else:
+                    for j, i in enumerate(chunk):
+                        out[i].copy_(y[j])
         return out
 
     def get_speaker_embeddings(self, wavs):

@@ -386,8 +386,9 @@ bool make_plan(const tdx_mf2* h, int B, int T, Plan& P) {
     P.splits = (P.S + P.kchunk - 1) / P.kchunk;
     P.nblk_enc = (P.S + ENC_TOK - 1) / ENC_TOK;
     P.nblk_gn = (P.S + 63) / 64;
-    P.nchunk1 = (P.S + DDN_TS - 1) / DDN_TS;
-    P.nchunk2 = 2 * ((P.S + 2 * DDN_TS - 1) / (2 * DDN_TS));
+    const int ts = ddn_ts(B, P.S);
+    P.nchunk1 = (P.S + ts - 1) / ts;
+    P.nchunk2 = 2 * ((P.S + 2 * ts - 1) / (2 * ts));
     const size_t M = (size_t)P.M;
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += al(n); return o; };
@@ -439,14 +440,21 @@ inline dim3 rows4(long M) { return dim3((unsigned)((M + 3) / 4)); }
 // conv17 launch helper
 template <int MODE>
 int launch_conv17(Conv17Args a, int B, hipStream_t st) {
-    constexpr int TPT = (MODE == 2 || MODE == 3) ? 32 : 128;
+    constexpr int TPT = (MODE == 2 || MODE == 3) ? 32 : 128;      // tokens per thread
+    constexpr int TPT_SMALL = TPT / 4;                             // small problems: 4x the blocks (one window per call: 68-136 blocks otherwise)
     const int quads = a.C / 4;
     const int qb = quads >= 256 ? 256 : quads;      // 256, 128 or 32
     const int ty = 256 / qb;
     dim3 block(qb, ty);
     const int s_lim = MODE >= 2 ? a.Sp : a.S;
-    dim3 grid(quads / qb, (s_lim + ty * TPT - 1) / (ty * TPT), B);
-    hipLaunchKernelGGL((conv17_kernel<MODE, TPT>), grid, block, 0, st, a);
+    const long nblk = (long)(quads / qb) * ((s_lim + ty * TPT - 1) / (ty * TPT)) * B;
+    if (nblk < 512) {
+        dim3 grid(quads / qb, (s_lim + ty * TPT_SMALL - 1) / (ty * TPT_SMALL), B);
+        hipLaunchKernelGGL((conv17_kernel<MODE, TPT_SMALL>), grid, block, 0, st, a);
+    } else {
+        dim3 grid(quads / qb, (s_lim + ty * TPT - 1) / (ty * TPT), B);
+        hipLaunchKernelGGL((conv17_kernel<MODE, TPT>), grid, block, 0, st, a);
+    }
     LAUNCH_CHECK();
     return TDX_OK;
 }
@@ -568,14 +576,15 @@ int attention_core_h3(const unsigned char* qkP, const float* qks, const unsigned
 
 int ddn_core(const float* p, int B, int S, const float* w1T, const float* w2T, const float* ing, const float* inb,
              const float* pre, float* c1, float* c2, float* stat1, float* stat2, double* part, hipStream_t st) {
-    const int nchunk1 = (S + DDN_TS - 1) / DDN_TS, nchunk2 = 2 * ((S + 2 * DDN_TS - 1) / (2 * DDN_TS));
-    hipLaunchKernelGGL(ddn_conv1_kernel, dim3(nchunk1, B), dim3(256), 0, st, p, w1T, c1, part, S, nchunk1);
+    const int ts = ddn_ts(B, S);
+    const int nchunk1 = (S + ts - 1) / ts, nchunk2 = 2 * ((S + 2 * ts - 1) / (2 * ts));
+    hipLaunchKernelGGL(ddn_conv1_kernel, dim3(nchunk1, B), dim3(256), 0, st, p, w1T, c1, part, S, nchunk1, ts);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(in_finalize_kernel, dim3(B), dim3(256), 0, st, part, stat1, nchunk1, S);
+    hipLaunchKernelGGL(in_finalize_kernel, dim3(B, 4), dim3(256), 0, st, part, stat1, nchunk1, S);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(ddn_conv2_kernel, dim3(nchunk2, B), dim3(256), 0, st, c1, p, stat1, ing, inb, pre, w2T, c2, part, S, nchunk2);
+    hipLaunchKernelGGL(ddn_conv2_kernel, dim3(nchunk2, B), dim3(256), 0, st, c1, p, stat1, ing, inb, pre, w2T, c2, part, S, nchunk2, ts);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(in_finalize_kernel, dim3(B), dim3(256), 0, st, part, stat2, nchunk2, S);
+    hipLaunchKernelGGL(in_finalize_kernel, dim3(B, 4), dim3(256), 0, st, part, stat2, nchunk2, S);
     LAUNCH_CHECK();
     return TDX_OK;
 }
@@ -1208,7 +1217,8 @@ int tdx_cal_attention(const float* quad_q, const float* lin_q, const float* quad
 size_t tdx_dilated_dense_net_workspace_bytes(int B, int S) {
     if (B < 1 || S < 1) return 0;
     const size_t M = (size_t)B * S;
-    const int nchunk1 = (S + DDN_TS - 1) / DDN_TS, nchunk2 = 2 * ((S + 2 * DDN_TS - 1) / (2 * DDN_TS));
+    const int ts = ddn_ts(B, S);
+    const int nchunk1 = (S + ts - 1) / ts, nchunk2 = 2 * ((S + 2 * ts - 1) / (2 * ts));
     const int nc = nchunk1 > nchunk2 ? nchunk1 : nchunk2;
     return (al(M * 256) * 2 + al((size_t)B * 512) * 2 + al(39 * 256) + al(39 * 512) + al((size_t)B * nc * 256 * 2 * 2)) * sizeof(float);
 }

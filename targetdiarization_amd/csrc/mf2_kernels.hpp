@@ -217,13 +217,15 @@ __global__ __launch_bounds__(256) void xplanes_kernel(const float* __restrict__ 
 // Statistics: per (b, chunk, channel) partial (sum, sumsq) in double -> in_finalize_kernel.
 // w1T [39][256]; w2T [39][2][256].
 // ---------------------------------------------------------------------------------------
-constexpr int DDN_TS = 256;   // tokens per block (conv1) ; conv2 handles DDN_TS tokens of one parity
+constexpr int DDN_TS = 256;   // tokens per block (conv1) ; conv2 handles `ts` tokens of one parity
+// small problems (one window per call: 68 blocks of 256 tokens for 256 CUs) use shorter token chunks so that the grid fills the chip
+inline int ddn_ts(int B, int S) { return ((long)B * ((S + DDN_TS - 1) / DDN_TS) >= 512) ? DDN_TS : 64; }
 __global__ __launch_bounds__(256) void ddn_conv1_kernel(const float* __restrict__ p, const float* __restrict__ w1T,
                                                          float* __restrict__ c1, double* __restrict__ part, int S,
-                                                         int nchunk) {
+                                                         int nchunk, int ts) {
     constexpr int K = 39, U = 8, W = K - 1 + U;
-    const int ch = threadIdx.x, b = blockIdx.y, s_begin = blockIdx.x * DDN_TS;
-    const int s_end = min(s_begin + DDN_TS, S);
+    const int ch = threadIdx.x, b = blockIdx.y, s_begin = blockIdx.x * ts;
+    const int s_end = min(s_begin + ts, S);
     const float* in = p + (long)b * S * 256 + ch;
     float w[K];
 #pragma unroll
@@ -271,20 +273,30 @@ __global__ __launch_bounds__(256) void ddn_conv1_kernel(const float* __restrict_
     part[(((long)b * nchunk + blockIdx.x) * 256 + ch) * 2 + 1] = sq;
 }
 
-// stat[b][c] = (mean, rstd) with biased variance over S tokens, eps 1e-5 (InstanceNorm2d)
+// stat[b][c] = (mean, rstd) with biased variance over S tokens, eps 1e-5 (InstanceNorm2d).  grid (B, 4): a block owns 64 channels,
+// its four waves walk the chunk partials in parallel (a one-window call has ~270 short chunks and B = 1: one block with one
+// thread per channel took 20-50 us, 48 times per forward)
 __global__ __launch_bounds__(256) void in_finalize_kernel(const double* __restrict__ part, float* __restrict__ stat,
                                                            int nchunk, int S) {
-    const int b = blockIdx.x, ch = threadIdx.x;
+    __shared__ double red[4][64][2];
+    const int b = blockIdx.x, ch = blockIdx.y * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
     double s = 0, q = 0;
-    for (int i = 0; i < nchunk; ++i) {
+    for (int i = g; i < nchunk; i += 4) {
         s += part[(((long)b * nchunk + i) * 256 + ch) * 2];
         q += part[(((long)b * nchunk + i) * 256 + ch) * 2 + 1];
     }
-    const double mean = s / S;
-    double var = q / S - mean * mean;
-    if (var < 0) var = 0;
-    stat[(b * 256 + ch) * 2 + 0] = (float)mean;
-    stat[(b * 256 + ch) * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
+    red[g][threadIdx.x & 63][0] = s; red[g][threadIdx.x & 63][1] = q;
+    __syncthreads();
+    if (g == 0) {
+        const int l = threadIdx.x;
+        s = (red[0][l][0] + red[1][l][0]) + (red[2][l][0] + red[3][l][0]);
+        q = (red[0][l][1] + red[1][l][1]) + (red[2][l][1] + red[3][l][1]);
+        const double mean = s / S;
+        double var = q / S - mean * mean;
+        if (var < 0) var = 0;
+        stat[(b * 256 + ch) * 2 + 0] = (float)mean;
+        stat[(b * 256 + ch) * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
+    }
 }
 
 // conv2: blockIdx.x = chunk*2 + parity; thread j = output channel.
@@ -292,12 +304,12 @@ __global__ __launch_bounds__(256) void ddn_conv2_kernel(const float* __restrict_
                                                          const float* __restrict__ stat1, const float* __restrict__ in_g,
                                                          const float* __restrict__ in_b, const float* __restrict__ prelu,
                                                          const float* __restrict__ w2T, float* __restrict__ c2,
-                                                         double* __restrict__ part, int S, int nchunk2) {
+                                                         double* __restrict__ part, int S, int nchunk2, int ts) {
     constexpr int K = 39, U = 4, W = K - 1 + U;
     const int j = threadIdx.x, b = blockIdx.y;
     const int par = blockIdx.x & 1, chunk = blockIdx.x >> 1;
     // this block's outputs: tokens s = s_begin + 2*i (same parity), i in [0, DDN_TS)
-    const int s_begin = chunk * (2 * DDN_TS) + par;
+    const int s_begin = chunk * (2 * ts) + par;
     const bool from_c1 = j < 128;
     const int ic = from_c1 ? 2 * j : 2 * (j - 128);
     const float* src = (from_c1 ? c1 : p) + (long)b * S * 256 + ic;
@@ -338,7 +350,7 @@ __global__ __launch_bounds__(256) void ddn_conv2_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < U; ++i) nx[i] = ldraw(s_begin + 2 * i + 38);
     double sum = 0.0, sq = 0.0;
-    for (int i0 = 0; i0 < DDN_TS; i0 += U) {
+    for (int i0 = 0; i0 < ts; i0 += U) {
         if (s_begin + 2 * i0 >= S) break;
 #pragma unroll
         for (int i = 0; i < U; ++i) win[K - 1 + i] = fix(nx[i], s_begin + 2 * (i0 + i) + 38);

@@ -42,8 +42,8 @@ def gather_embeddings(local: torch.Tensor, n_total: int, rank: int, world: int, 
     out = out.view(world, max_n, streams, D)
     full = torch.empty(n_total, streams, D, dtype=local.dtype, device=local.device)
     for r in range(world):
-        idx = shard_indices(n_total, r, world)
-        full[idx] = out[r, : len(idx)]
+        n_r = len(shard_indices(n_total, r, world))
+        full[r::world] = out[r, :n_r]          # (a strided slice, not an index list: no host-blocking index upload)
     return full.view(n_total * streams, D)
 
 

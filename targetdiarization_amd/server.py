@@ -1,0 +1,182 @@
+"""Serving shell: the wire format of the reference's FastAPI app (main.py:46-288) around the MI355X
+`TargetDiarization` — `GET /`, `GET /health`, `POST /diarization/infer` (multipart upload: audio_file, optional target_file; query:
+sampling_rate, is_single, output_target_audio) and `WS /diarization/stream` (config -> optional target_audio -> audio_chunk* -> end).
+
+Differences, all on the host side: uploads are decoded with the stdlib `wave` module (16-bit PCM; the reference hands the temp file
+to audioread) and resampled on the device; the multipart body is parsed with the stdlib `email` parser (python-multipart is not a
+dependency); the streaming endpoint buffers `max_buffer_duration` seconds (default 10) per inference instead of the reference's
+silero-VAD router (TargetDiarizationStream.py:81-171: third-party VAD) — a `vad` plug-in of the model still trims the target clip.
+
+    app = create_app(model)          # model: targetdiarization_amd.target_diarization.TargetDiarization (or None: 500 on infer)
+    uvicorn.run(app, host="0.0.0.0", port=8000)
+"""
+
+import base64
+import io
+import time
+import wave
+from email.parser import BytesParser
+from email.policy import HTTP
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+
+
+def format_speaker_info(speaker_id: str, target_speaker_id: str) -> str:
+    """main.py:62-68"""
+    if speaker_id == target_speaker_id:
+        return "target"
+    if speaker_id == "-1":
+        return "uncertain"
+    return "other"
+
+
+def audio_to_base64(audio_data: Optional[np.ndarray]) -> str:
+    """main.py:72-79: float32 -> int16 (x 32767) -> base64"""
+    if audio_data is None:
+        return ""
+    if audio_data.dtype == np.float32:
+        audio_data = (audio_data * 32767).astype(np.int16)
+    return base64.b64encode(audio_data.tobytes()).decode("utf-8")
+
+
+def decode_wav(data: bytes):
+    """PCM16 .wav bytes -> (float32 [n] or [n, ch] in [-1, 1], sampling rate)"""
+    with wave.open(io.BytesIO(data), "rb") as w:
+        if w.getsampwidth() != 2:
+            raise ValueError("only 16-bit PCM .wav uploads are decoded here")
+        x = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).astype(np.float32) / 32768.0
+        ch, sr = w.getnchannels(), w.getframerate()
+    return (x.reshape(-1, ch) if ch > 1 else x), sr
+
+
+def parse_multipart(content_type: str, body: bytes) -> Dict[str, Dict[str, Any]]:
+    """multipart/form-data -> {field name: {"filename": str | None, "data": bytes}}"""
+    msg = BytesParser(policy=HTTP).parsebytes(b"Content-Type: " + content_type.encode() + b"\r\nMIME-Version: 1.0\r\n\r\n" + body)
+    out = {}
+    if not msg.is_multipart():
+        return out
+    for part in msg.iter_parts():
+        name = part.get_param("name", header="content-disposition")
+        if name:
+            out[name] = {"filename": part.get_filename(), "data": part.get_payload(decode=True) or b""}
+    return out
+
+
+def build_response_data(target_spk: str, final_result: List[dict], target_audio, output_target_audio: bool) -> Dict[str, Any]:
+    """main.py:196-213: the `data` object of a successful /diarization/infer response"""
+    results = [{"speaker": r["speaker"], "speaker_type": format_speaker_info(r["speaker"], target_spk), "timerange": [float(t) for t in r["timerange"]],
+                "text": r["text"], "type": r["type"], "score": float(r.get("score", -1.0))} for r in final_result]
+    data = {
+        "target_speaker_id": target_spk,
+        "total_speakers": len(set(r["speaker"] for r in final_result if r["speaker"] != "-1")),
+        "results": results,
+        "statistics": {
+            "total_duration": round(max(r["timerange"][1] for r in final_result) if final_result else 0.0, 3),
+            "target_speaker_duration": round(sum(r["timerange"][1] - r["timerange"][0] for r in final_result if r["speaker"] == target_spk), 3),
+            "other_speakers_duration": round(sum(r["timerange"][1] - r["timerange"][0] for r in final_result
+                                                 if r["speaker"] != target_spk and r["speaker"] != "-1"), 3),
+        },
+    }
+    if output_target_audio and target_audio is not None:
+        data["target_audio_base64"] = audio_to_base64(np.asarray(target_audio))
+    return data
+
+
+def create_app(model=None, max_buffer_duration: float = 10.0):
+    from fastapi import FastAPI, HTTPException, Request, WebSocket, WebSocketDisconnect
+    from fastapi.middleware.cors import CORSMiddleware
+
+    app = FastAPI(title="Target Diarization API")
+    app.add_middleware(CORSMiddleware, allow_origins=["*"], allow_credentials=True, allow_methods=["*"], allow_headers=["*"])
+    app.state.model = model
+
+    def to16k(x, sr):
+        if x.ndim > 1:
+            x = x.mean(axis=1).astype(np.float32)
+        if sr != 16000:
+            x = app.state.model.hp.ap.audio_resample(x, sr, 16000, output_audio_only=True)
+        return x
+
+    @app.get("/")
+    async def root():
+        return {"message": "Target Diarization API", "version": "1.0.0",
+                "endpoints": {"inference": "/diarization/infer", "streaming": "/diarization/stream", "health": "/health"}}
+
+    @app.get("/health")
+    async def health_check():
+        return {"status": "healthy", "model_loaded": app.state.model is not None, "timestamp": int(time.time())}
+
+    @app.post("/diarization/infer")
+    async def diarization_infer(request: Request, sampling_rate: int = 16000, is_single: bool = False, output_target_audio: bool = True):
+        start = time.time()
+        if app.state.model is None:
+            raise HTTPException(status_code=500, detail="Model not loaded")
+        try:
+            form = parse_multipart(request.headers.get("content-type", ""), await request.body())
+            if "audio_file" not in form:
+                raise HTTPException(status_code=422, detail="audio_file is required")
+            audio, sr = decode_wav(form["audio_file"]["data"])
+            audio = to16k(audio, sr)
+            target = None
+            if "target_file" in form and form["target_file"]["data"]:
+                t, tsr = decode_wav(form["target_file"]["data"])
+                target = to16k(t, tsr)
+            target_spk, final_result, target_audio = app.state.model.infer(wav_file=audio, target_file=target, sampling_rate=16000,
+                                                                           is_single=is_single, output_target_audio=output_target_audio)
+            return {"success": True, "data": build_response_data(target_spk, final_result, target_audio, output_target_audio), "error": None,
+                    "processing_time": round(time.time() - start, 3)}
+        except HTTPException:
+            raise
+        except Exception as e:                       # main.py:222-233: errors are reported in the body, not as HTTP errors
+            return {"success": False, "data": None, "error": f"Inference failed: {e}", "processing_time": round(time.time() - start, 3)}
+
+    @app.websocket("/diarization/stream")
+    async def diarization_stream(websocket: WebSocket):
+        await websocket.accept()
+        try:
+            if app.state.model is None:
+                await websocket.send_json({"type": "error", "message": "Model not loaded"})
+                return
+            config = (await websocket.receive_json()).get("data", {})
+            target = None
+            if config.get("has_target_file", False):
+                msg = await websocket.receive_json()
+                if msg.get("type") == "target_audio":
+                    target = np.frombuffer(base64.b64decode(msg.get("data")), dtype=np.int16).astype(np.float32) / 32767.0
+            await websocket.send_json({"type": "config_ack", "data": {"config": config, "target_file_loaded": target is not None}})
+            buf, offset = [], 0.0
+            limit = int(float(config.get("max_buffer_duration", max_buffer_duration)) * 16000)
+
+            async def flush():
+                nonlocal buf, offset
+                if not buf:
+                    return
+                audio = np.concatenate(buf)
+                buf = []
+                spk, res, _ = app.state.model.infer(wav_file=audio, target_file=target, sampling_rate=16000,
+                                                    is_single=bool(config.get("is_single", False)), output_target_audio=False)
+                for seg in res:
+                    await websocket.send_json({"type": "segment_result", "data": {"target_speaker_id": spk, "segment": {
+                        "speaker": seg["speaker"], "speaker_type": format_speaker_info(seg["speaker"], spk),
+                        "timerange": [round(seg["timerange"][0] + offset, 3), round(seg["timerange"][1] + offset, 3)], "text": seg["text"], "type": seg["type"]}}})
+                offset += audio.shape[0] / 16000.0
+            while True:
+                msg = await websocket.receive_json()
+                if msg.get("type") == "audio_chunk":
+                    buf.append(np.frombuffer(base64.b64decode(msg.get("data")), dtype=np.int16).astype(np.float32) / 32767.0)
+                    if sum(b.shape[0] for b in buf) >= limit:
+                        await flush()
+                elif msg.get("type") == "end":
+                    break
+            await flush()
+            await websocket.send_json({"type": "status", "message": "completed"})
+        except WebSocketDisconnect:
+            pass
+        except Exception as e:
+            try:
+                await websocket.send_json({"type": "error", "message": f"Processing error: {e}"})
+            except Exception:
+                pass
+
+    return app

@@ -105,3 +105,28 @@ def test_infer_with_device_decoder_and_denoiser(gold, sd2):
     assert spk in ("0", "1") and res
     texts = [r["text"] for r in res]
     assert any(t for t in texts) and all(t == "" or t.startswith("w") for t in texts)      # recipe weights: arbitrary tokens, but tokens
+
+
+def test_serving_shell_over_the_device_model(gold, sd2):
+    """N4: POST /diarization/infer with the config-1 assets as multipart uploads gives the same decisions as a direct infer()"""
+    pytest.importorskip("fastapi")
+    from fastapi.testclient import TestClient
+    from targetdiarization_amd.server import create_app
+    from targetdiarization_amd.target_diarization import TargetDiarization
+    from targetdiarization_amd.weights import recipe_eres2netv2_state_dict
+    sd_rows = {"text": [[0.0, 3.0, 0], [2.4, 5.5, 1], [5.5, 8.6, 0]]}
+    od = [(0.0, 3.0, "SPEAKER_00"), (2.4, 5.5, "SPEAKER_01"), (5.5, 8.6, "SPEAKER_00")]
+    td = TargetDiarization(cuda_device=0, sep_state_dict=sd2, spk_state_dict=recipe_eres2netv2_state_dict(0), sd_pipeline=lambda a: sd_rows,
+                           od_pipeline=lambda a: od, target_similarity_threshold=0.0)
+    spk, res, aud = td.infer(_load(gold, "chat_mix.wav"), _load(gold, "female_a.wav"))
+    c = TestClient(create_app(td))
+    with open(os.path.join(gold, "chat_mix.wav"), "rb") as f, open(os.path.join(gold, "female_a.wav"), "rb") as g:
+        j = c.post("/diarization/infer", files={"audio_file": ("m.wav", f.read(), "audio/wav"), "target_file": ("t.wav", g.read(), "audio/wav")}).json()
+    assert j["success"], j["error"]
+    d = j["data"]
+    assert d["target_speaker_id"] == spk and len(d["results"]) == len(res)
+    assert [(r["speaker"], r["type"]) for r in d["results"]] == [(r["speaker"], r["type"]) for r in res]
+    assert np.allclose([r["timerange"] for r in d["results"]], [r["timerange"] for r in res])
+    import base64
+    pcm = np.frombuffer(base64.b64decode(d["target_audio_base64"]), dtype=np.int16)
+    assert pcm.shape[0] == aud.shape[0] and np.abs(pcm.astype(np.float32) / 32767.0 - aud).max() < 1e-3

@@ -111,7 +111,18 @@ struct H3Args {
     int cv_Hin, cv_Win, cv_Hout, cv_Wout, cv_stride, cv_ntaps, cv_cin;
     const unsigned char* zero_row;
     int dbg;                     // diagnostics (env TDX_H3_DEBUG, timing only, wrong results): 1 = no epilogue
+    unsigned long long* stamps;  // diagnostics (builds with -DTDX_H3_STAMPS only): 8 x u64 per block, see H3_STAMP
 };
+
+// in-kernel time stamps (diagnostic builds): wave 0 lane 0 of every block records the 100 MHz wall clock at phase boundaries
+#ifdef TDX_H3_STAMPS
+#define H3_STAMP(i) do { if (g.stamps && threadIdx.x == 0) g.stamps[(long)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#define H3_STAMP_HW() do { if (g.stamps && threadIdx.x == 0) g.stamps[(long)blockIdx.x * 8 + 7] = \
+    (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); } while (0)
+#else
+#define H3_STAMP(i) do {} while (0)
+#define H3_STAMP_HW() do {} while (0)
+#endif
 
 inline H3Seg h3_seg(const void* A, const float* sa, long lda, const void* B, const float* sb, long ldb, int K) {
     H3Seg s{};
@@ -143,6 +154,37 @@ __device__ __forceinline__ f16x8 h3_frag(const unsigned char* p) {
     }
 }
 
+// ds_read_b64_tr_b16 through INLINE ASM.  The compiler's waitcnt pass puts `s_waitcnt vmcnt(0)` in front of the builtin form
+// whenever an LDS-DMA is outstanding (it cannot tell that the read does not touch the DMA's destination; plain ds_read_b128
+// loads are disambiguated, the builtin is not): the ring then waits, every stage, for the DMA it has just issued.  The asm
+// form is invisible to that pass — and to its lgkmcnt bookkeeping: the raw halves must go through h3_tr_fence (an
+// `s_waitcnt lgkmcnt(0)` tied to the registers) before anything reads them, and no instruction may touch them in between
+// (tools/asm_tr_hazard.py checks the ISA).  LDS returns in order, so the compiler's own lgkmcnt counts stay conservative.
+struct H3TrRaw { uint2 lo, hi; };         // k = 8h .. 8h+3 | 8h+4 .. 8h+7 of the lane's column
+__device__ __forceinline__ unsigned h3_lds_addr(const unsigned char* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
+}
+template <int OFF>
+__device__ __forceinline__ void h3_tr_read(H3TrRaw& r, unsigned a) {   // a + OFF = LDS address of (k row 8h+q, 4 columns) for this lane
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r.lo) : "v"(a), "n"(OFF) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r.hi) : "v"(a), "n"(OFF + 4096) : "memory");
+}
+__device__ __forceinline__ f16x8 h3_tr_value(const H3TrRaw& r) {       // (after the fence)
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(f16x8, u4{r.lo.x, r.lo.y, r.hi.x, r.hi.y});
+}
+template <int N>
+__device__ __forceinline__ void h3_tr_fence(H3TrRaw (&r)[N]) {
+    static_assert(N == 2 || N == 4 || N == 8, "fence over 2, 4 or 8 raw fragments");
+    if constexpr (N == 8)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0].lo), "+v"(r[0].hi), "+v"(r[1].lo), "+v"(r[1].hi), "+v"(r[2].lo), "+v"(r[2].hi), "+v"(r[3].lo), "+v"(r[3].hi),
+                     "+v"(r[4].lo), "+v"(r[4].hi), "+v"(r[5].lo), "+v"(r[5].hi), "+v"(r[6].lo), "+v"(r[6].hi), "+v"(r[7].lo), "+v"(r[7].hi) :: "memory");
+    else if constexpr (N == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0].lo), "+v"(r[0].hi), "+v"(r[1].lo), "+v"(r[1].hi), "+v"(r[2].lo), "+v"(r[2].hi), "+v"(r[3].lo), "+v"(r[3].hi) :: "memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0].lo), "+v"(r[0].hi), "+v"(r[1].lo), "+v"(r[1].hi) :: "memory");
+}
+
 // Per-lane fragment addressing inside a stage buffer.
 //   row-major planes: A tile tm, plane pl at  a0 + tm*2048 + apl[pl];  B tile tn at  b0 + tn*8192 + bpl[pl]
 //   K-major planes  : A tile tm, plane pl at  at[tm] + pl*256;          B tile tn at  b0 + tn*512 + pl*256
@@ -167,6 +209,9 @@ template <bool A_TR, bool B_TR, bool FULLN, bool NEXT, bool ISSUE, int PH, bool 
 __device__ __forceinline__ void h3_stage(f32x16 (&acc)[4][2], f16x8 (&ah)[4], f16x8 (&al)[4], f16x8 (&bh)[2], f16x8 (&bl)[2],
                                          const unsigned char* nxt, const H3Frag& f,
                                          const unsigned char* const (&gp)[4], long goff, unsigned char* dmad) {
+    // (K-major operands: the builtin transposing reads are preceded by a compiler-inserted s_waitcnt vmcnt(0) — see h3_tr_read;
+    //  the asm form was measured here too: -2 % on the attention launch, +30 % on the M = 128 lin_k^T [v|u] launch, whose four
+    //  computing waves lose the pinned issue order.  The model's attention launch runs on gemm_h3a.hpp, which uses the asm form.)
     f16x8 nbh[2], nbl[2];
     if constexpr (NEXT) {
 #pragma unroll
@@ -381,6 +426,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
     }
     const int m0 = bm * H3_BM;
     const int n0 = PAIRED ? bn * (H3_BN / 2) : bn * H3_BN;
+    H3_STAMP(0); H3_STAMP_HW();
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -540,6 +586,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
         if (tid < 256) { sal[tid] = sa_own; if constexpr (HAS_ROW) rwl[tid] = rw_own; }
         if (nkt0 >= 4) H3_WAIT_VM(12); else if (nkt0 == 3) H3_WAIT_VM(8); else if (nkt0 == 2) H3_WAIT_VM(4); else H3_WAIT_VM(0);
         H3_BARRIER();
+        H3_STAMP(1);
         f16x8 ah[4], al[4], bh[2], bl[2];
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
@@ -716,6 +763,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
     // `if (m < M)` blocks make the compiler's waitcnt pass re-wait vmcnt(0) at every block entry, i.e. one store round
     // trip per store: 17 us per tile; (ii) row scales and the functor's row() values come from LDS (staged before the
     // prologue); (iii) column constants are fetched before the first store and aux() operands half a row block ahead.
+    H3_STAMP(2);
     if (g.dbg & 1) {                    // (timing: no epilogue)
         float x = 0.f;
 #pragma unroll
@@ -964,6 +1012,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
                 }
             }
             __syncthreads();
+            H3_STAMP(3);
             const int hw = lane >> 5, l32 = lane & 31;
             unsigned char* const pbase = po.planes + (long)n0 * 4;
 #pragma unroll 4
@@ -1096,6 +1145,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
     if constexpr (epi_has_full<Epi>::value) whole = whole && epi.full(z, m0);
     if constexpr (epi_has_plout<Epi>::value) { if (whole) epilogue_pl(std::false_type{}); else epilogue_pl(std::true_type{}); }
     else { if (whole) epilogue(std::false_type{}); else epilogue(std::true_type{}); }
+    H3_STAMP(4);
 }
 
 template <bool A_TR, bool B_TR, bool PAIRED, bool TWOSEG, class Epi, int VARIANT = 0, bool A_CONV = false>

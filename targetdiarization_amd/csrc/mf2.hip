@@ -19,6 +19,7 @@
 #include "gemm.hpp"
 #include "gemm_x6.hpp"
 #include "gemm_h3.hpp"
+#include "gemm_h3a.hpp"
 #include "gemm_h3p.hpp"
 #include "mf2_kernels.hpp"
 #include "tdx_common.hpp"
@@ -499,6 +500,13 @@ int attention_core(const float* qk4, const float* vu, int B, int S, int E, int s
     return TDX_OK;
 }
 
+// A/B switch for the half-height two-blocks-per-CU attention kernel (gemm_h3a.hpp; bit-identical to the wide kernel).
+// TDX_H3A=0 selects the wide 256-row kernel.
+inline bool use_h3a() {
+    static const bool on = [] { const char* e = getenv("TDX_H3A"); return e ? atoi(e) != 0 : true; }();
+    return on;
+}
+
 // The same attention on the split-f16 x3 core (gemm_h3.hpp), E = 1024:
 //   qkP : the four heads as planes in [4][B][Sp] x 512 B slots (conv17 MODE 3): quad_q, lin_q, quad_k row-major
 //         with row scales qks[3][B*Sp]; lin_k K-major with the static scale st[1]
@@ -535,7 +543,9 @@ int attention_core_h3(const unsigned char* qkP, const float* qks, const unsigned
         g.seg[0].kchunk = kchunk; g.seg[0].ktotal = Sp;
         g.nseg = 1; g.M = QK; g.N = 2 * E;
         EpiStore e{slab, 2L * E, (long)QK * 2 * E};
-        if (tdx::launch_gemm_h3x<false, true, false, false>(g, B * splits, e, st_) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+        if (use_h3a() && tdx::h3a_fits<false>(g, false)) {      // 128-row tiles, two blocks per CU: every wave has rows
+            if (tdx::launch_gemm_h3a<false>(g, B * splits, e, st_) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+        } else if (tdx::launch_gemm_h3x<false, true, false, false>(g, B * splits, e, st_) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
         const long per = (long)QK * 2 * E;
         const int nb = (int)((per / 4 + 255) / 256);
         float* bmax = kvus + B;          // [B][nb] block maxima
@@ -558,7 +568,32 @@ int attention_core_h3(const unsigned char* qkP, const float* qks, const unsigned
         g.seg[1].strideB = (long)QK * 4 * 2 * E; g.seg[1].strideB2 = 0;
         g.seg[1].strideSB = 1; g.seg[1].strideSB2 = 0;
         g.nseg = 2; g.M = 256; g.N = E; g.pair_off = E;
+        {   // (diagnostic, timing only, wrong results: TDX_H3_DEBUG & 2 = every group reads the first group's v|u rows — an L2-resident B operand)
+            static const int dbg = [] { const char* e = getenv("TDX_H3_DEBUG"); return e ? atoi(e) : 0; }();
+            if (dbg & 2) { g.seg[0].strideB = 0; g.seg[0].strideB2 = 0; }
+        }
+#ifdef TDX_H3_STAMPS
+        // diagnostic build: the 4th config-2-sized attention launch records per-block time stamps into $TDX_H3_STAMPS (a file)
+        static int stamp_calls = 0;
+        static unsigned long long* stamp_buf = nullptr;
+        const long stamp_blocks = 8L * ((B * G + 7) / 8) * (use_h3a() ? 16 : 8);
+        const bool stamp_now = oP && getenv("TDX_H3_STAMPS") && B * G >= 900 && ++stamp_calls == 4;
+        if (stamp_now) {
+            hipMalloc((void**)&stamp_buf, stamp_blocks * 64);
+            hipMemsetAsync(stamp_buf, 0, stamp_blocks * 64, st_);
+            g.stamps = stamp_buf;
+        }
+        struct StampDump { bool on; long nb; unsigned long long* buf; hipStream_t s;
+            ~StampDump() { if (!on) return; hipStreamSynchronize(s); std::vector<unsigned long long> h(nb * 8);
+                hipMemcpy(h.data(), buf, nb * 64, hipMemcpyDeviceToHost); FILE* f = fopen(getenv("TDX_H3_STAMPS"), "wb");
+                if (f) { fwrite(h.data(), 8, h.size(), f); fclose(f); } } } stamp_dump{stamp_now, stamp_blocks, stamp_buf, st_};
+#endif
         if (oP) {             // the model: gate operands from the planes, o written as planes with per-segment scales / sums of squares
+            if (use_h3a()) {  // half-height tiles, two blocks per CU (gemm_h3a.hpp): one block's epilogue under the other's MFMAs
+                if (tdx::launch_gemm_h3a<true>(g, B * G, EpiAttnGatePlOut{vuP, st, oP, os, oss, (long)B * S, G, S, Sp, E}, st_) != hipSuccess)
+                    return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+                return TDX_OK;
+            }
             if (tdx::launch_gemm_h3x<false, true, true, true>(g, B * G, EpiAttnGatePlOut{vuP, st, oP, os, oss, (long)B * S, G, S, Sp, E}, st_) != hipSuccess)
                 return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
             return TDX_OK;

@@ -1,0 +1,54 @@
+"""per-block phase times of the attention launch from in-kernel wall-clock stamps (diagnostic build of the library with
+-DTDX_H3_STAMPS: `python tools/h3_stamps.py build` here, then on the GPU box `TDX_H3A=0|1 python tools/h3_stamps.py run <tag>`)."""
+import sys, os, subprocess
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = os.path.join(ROOT, "targetdiarization_amd")
+LIBS = os.path.join(PKG, "libtdx_stamps.so")
+if sys.argv[1] == "build":
+    from targetdiarization_amd import build
+    objs = []
+    for src in build.SOURCES:
+        obj = os.path.join(build.OBJ, os.path.splitext(src)[0] + ("_stamps.o" if src == "mf2.hip" else ".o"))
+        if src == "mf2.hip":
+            subprocess.run([build.HIPCC] + build.FLAGS + ["-DTDX_H3_STAMPS", "-c", os.path.join(build.CSRC, src), "-o", obj], check=True)
+        objs.append(obj)
+    subprocess.run([build.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIBS] + objs, check=True)
+    print(LIBS); sys.exit(0)
+import numpy as np
+tag = sys.argv[2]
+os.makedirs("gpurun_out", exist_ok=True)
+fn = f"gpurun_out/h3_stamps_{tag}.bin"
+if sys.argv[1] == "run":
+    os.environ["TDX_H3_STAMPS"] = fn
+    import torch
+    from targetdiarization_amd import _lib
+    _lib.LIB_PATH = LIBS
+    from targetdiarization_amd.separator import MossFormer2Separator
+    from targetdiarization_amd.weights import recipe_state_dict
+    sep = MossFormer2Separator(recipe_state_dict(0, 6), device="cuda:0")
+    g = torch.Generator().manual_seed(5)
+    xb = (torch.randn(30, 64000, generator=g) * 0.1).cuda()
+    sep(xb); torch.cuda.synchronize()
+a = np.fromfile(fn, dtype=np.uint64).reshape(-1, 8)
+a = a[a[:, 0] > 0]
+t = a[:, :5].astype(np.int64)
+t0 = t[:, 0].min()
+ph = np.diff(t, axis=1) / 100.0          # us (100 MHz)
+names = ["setup+prologue", "main loop", "epilogue phase 1", "epilogue phase 2"]
+print(f"{tag}: {len(a)} blocks, launch span {(t[:, 4].max() - t0) / 100.0:.1f} us")
+for i, n in enumerate(names):
+    print(f"  {n:18s} mean {ph[:, i].mean():7.2f} us  p10 {np.percentile(ph[:, i], 10):7.2f}  p90 {np.percentile(ph[:, i], 90):7.2f}")
+print(f"  block total        mean {(t[:, 4] - t[:, 0]).mean() / 100.0:7.2f} us")
+hw = a[:, 7]
+cu = ((hw >> 32) & 0xf) * 1000 + ((hw >> 13) & 7) * 100 + ((hw >> 12) & 1) * 50 + ((hw >> 8) & 0xf)      # xcc, se, sh, cu
+one = np.where(cu == cu[0])[0]
+order = one[np.argsort(t[one, 0])]
+print("  timeline of one CU (start, prologue done, loop done, phase 1 done, end; us from launch start):")
+for b in order[:12]:
+    print("    blk %6d wave-slot %2d: " % (b, hw[b] & 0xf) + "  ".join(f"{(x - t0) / 100.0:8.2f}" for x in t[b]))
+gaps = []
+for c in np.unique(cu):
+    idx = np.where(cu == c)[0]
+    st = np.sort(t[idx, 0]); en = np.sort(t[idx, 4])
+print(f"  CUs seen: {len(np.unique(cu))}, blocks per CU mean {len(a) / len(np.unique(cu)):.1f}")

@@ -590,6 +590,8 @@ int attention_core_h3(const unsigned char* qkP, const float* qks, const unsigned
 #endif
         if (oP) {             // the model: gate operands from the planes, o written as planes with per-segment scales / sums of squares
             if (use_h3a()) {  // half-height tiles, two blocks per CU (gemm_h3a.hpp): one block's epilogue under the other's MFMAs
+                static const bool swap = [] { const char* e = getenv("TDX_H3A_SWAP"); return e ? atoi(e) != 0 : false; }();
+                if (swap) std::swap(g.seg[0], g.seg[1]);      // (experiment: the L2-resident lin_q x Kvu segment first)
                 if (tdx::launch_gemm_h3a<true>(g, B * G, EpiAttnGatePlOut{vuP, st, oP, os, oss, (long)B * S, G, S, Sp, E}, st_) != hipSuccess)
                     return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
                 return TDX_OK;

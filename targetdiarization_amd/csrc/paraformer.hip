@@ -127,6 +127,73 @@ __global__ __launch_bounds__(256) void pf_softmax_kernel(float* __restrict__ sc,
     for (int c = lane; c < Sp; c += 64) row[c] = c < S ? row[c] * inv : 0.f;
 }
 
+// Attention of SHORT sequences in one launch (the reference's call pattern: one clip per call, 2 x 144 frames): scores, softmax
+// and P v for 8 query rows of one (batch, head) per block, fp32 FMAs — instead of two batched GEMM launches on tiles that are
+// mostly padding plus the softmax launch (44 us per layer at that size; this: ~8 us).  q, k, v: rows of 128-wide heads at
+// column h * 128 of matrices with their own pitches / per-batch strides; out [b][row][h * 128 + d].  Tk <= PF_FA_MAXT.
+constexpr int PF_FA_ROWS = 8, PF_FA_MAXT = 512;
+constexpr long PF_FA_WORK = 1L << 21;          // use when B * H * Tq * Tk <= this
+__global__ __launch_bounds__(256) void pf_attn_small_kernel(const float* __restrict__ q, long ldq, long sq, const float* __restrict__ k, long ldk, long sk,
+                                                            const float* __restrict__ v, long ldv, long sv, float* __restrict__ out, long ldo, long so,
+                                                            int Tq, int Tk, float scale) {
+    __shared__ __attribute__((aligned(16))) float qs[PF_FA_ROWS][DK];
+    __shared__ __attribute__((aligned(16))) float p[PF_FA_ROWS][PF_FA_MAXT];
+    const int b = blockIdx.z, h = blockIdx.y, r0 = blockIdx.x * PF_FA_ROWS, tid = threadIdx.x;
+    for (int i = tid; i < PF_FA_ROWS * DK; i += 256) {
+        const int r = i >> 7, d = i & 127;
+        qs[r][d] = q[(long)b * sq + (long)min(r0 + r, Tq - 1) * ldq + h * DK + d] * scale;
+    }
+    __syncthreads();
+    for (int j = tid; j < Tk; j += 256) {          // one key per thread: its dot products with the 8 query rows
+        const float4* kp = reinterpret_cast<const float4*>(k + (long)b * sk + (long)j * ldk + h * DK);
+        float acc[PF_FA_ROWS];
+#pragma unroll
+        for (int r = 0; r < PF_FA_ROWS; ++r) acc[r] = 0.f;
+#pragma unroll 8
+        for (int d4 = 0; d4 < DK / 4; ++d4) {
+            const float4 kv = kp[d4];
+#pragma unroll
+            for (int r = 0; r < PF_FA_ROWS; ++r) {
+                const float4 qv = *reinterpret_cast<const float4*>(&qs[r][4 * d4]);
+                acc[r] = fmaf(qv.x, kv.x, fmaf(qv.y, kv.y, fmaf(qv.z, kv.z, fmaf(qv.w, kv.w, acc[r]))));
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < PF_FA_ROWS; ++r) p[r][j] = acc[r];
+    }
+    __syncthreads();
+    {   // softmax of two rows per wave
+        const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            float* row = p[2 * w + rr];
+            float mx = -INFINITY;
+            for (int c = lane; c < Tk; c += 64) mx = fmaxf(mx, row[c]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            float sum = 0.f;
+            for (int c = lane; c < Tk; c += 64) { const float e = expf(row[c] - mx); row[c] = e; sum += e; }
+            sum = wave_sum(sum);
+            const float inv = 1.0f / sum;
+            for (int c = lane; c < Tk; c += 64) row[c] *= inv;
+        }
+    }
+    __syncthreads();
+    {   // P v: thread = (query row, 4 head channels)
+        const int r = tid >> 5, d4 = tid & 31;
+        const float* vp = v + (long)b * sv + h * DK + 4 * d4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int j = 0; j < Tk; ++j) {
+            const float4 vv = *reinterpret_cast<const float4*>(vp + (long)j * ldv);
+            const float pr = p[r][j];
+            acc.x = fmaf(pr, vv.x, acc.x); acc.y = fmaf(pr, vv.y, acc.y); acc.z = fmaf(pr, vv.z, acc.z); acc.w = fmaf(pr, vv.w, acc.w);
+        }
+        if (r0 + r < Tq) *reinterpret_cast<float4*>(out + (long)b * so + (long)(r0 + r) * ldo + h * DK + 4 * d4) = acc;
+    }
+}
+inline bool pf_attn_small_fits(int B, int Tq, int Tk) { return Tk <= PF_FA_MAXT && (long)B * H * Tq * Tk <= PF_FA_WORK; }
+
 struct EpiStoreZ { float* out; long ld; long strideZ;       // plain store per batch (split-K slabs)
     __device__ EpiNone col(int, int) const { return EpiNone{}; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
@@ -188,7 +255,7 @@ int lin3(const unsigned char* Ap, const float* As, const PfW3& W, int M, int N, 
 // slab [nsplit][M][N]; a small kernel sums the slab and applies the Linear's epilogue.  (Tried before: the exact-fp32 core for
 // these shapes — slower, 24.4 vs 18.8 ms for the 50-layer encoder at 2 x 145 frames.)
 constexpr long PF_SPLITK_ROWS = 512;
-constexpr size_t PF_SLAB = (size_t)PF_SPLITK_ROWS * 4096;          // floats: max over the Linears of nsplit * M * N
+constexpr size_t PF_SLAB = (size_t)PF_SPLITK_ROWS * 8192;          // floats: max over the Linears of nsplit * M * N
 enum { RK_BIAS = 0, RK_BIAS_RELU = 1, RK_BIAS_RES = 2, RK_OUTPROJ = 3, RK_STORE = 4 };
 template <int MODE>
 __global__ __launch_bounds__(256) void pf_splitk_reduce_kernel(const float* __restrict__ slab, int nsplit, long M, int N, const float* __restrict__ bias,
@@ -213,12 +280,24 @@ __global__ __launch_bounds__(256) void pf_splitk_reduce_kernel(const float* __re
     }
     *o = v;
 }
-inline int pf_nsplit(long M, int K) {          // chunks of >= 256 k (a multiple of 32), at most 8
+inline int pf_nsplit(long M, int K) {          // chunks of >= 128 k (a multiple of 32), at most 16: a block's fixed costs (ring fill,
+    // epilogue: ~9 us) outweigh its k loop at these sizes, and the launches have 8-32 tiles for 256 CUs
     if (M > PF_SPLITK_ROWS || K < 512) return 1;
-    int ns = K / 256; if (ns > 8) ns = 8;
+    int ns = K / 128; if (ns > 16) ns = 16;
     while (ns > 1 && (K % ns || (K / ns) % 32)) --ns;
     return ns;
 }
+// FSMN memory (depthwise conv over time, D = 512 channels): tokens per thread chosen so that the launch has >= 512 blocks when it can
+inline int pf_launch_fsmn(const Conv17Args& a, int T, int B, hipStream_t st) {
+    const dim3 block(128, 2);
+    const long rows = (long)T * B;
+    if (rows >= 512L * 256) hipLaunchKernelGGL((conv17_kernel<0, 128, KS>), dim3(1, (T + 2 * 128 - 1) / (2 * 128), B), block, 0, st, a);
+    else if (rows >= 512L * 32) hipLaunchKernelGGL((conv17_kernel<0, 16, KS>), dim3(1, (T + 2 * 16 - 1) / (2 * 16), B), block, 0, st, a);
+    else hipLaunchKernelGGL((conv17_kernel<0, 4, KS>), dim3(1, (T + 2 * 4 - 1) / (2 * 4), B), block, 0, st, a);
+    LAUNCH_CHECK();
+    return TDX_OK;
+}
+
 template <int MODE>
 int lin3_splitk(const unsigned char* Ap, const float* As, const PfW3& W, int M, int N, int K, int nsplit, float* slab, const float* bias, float* out,
                 long ldo, const float* mem, const float* resid, hipStream_t st) {
@@ -387,10 +466,13 @@ int tdx_pfenc_forward(tdx_pfenc* h, const float* feats, const int* lens_host, in
         {
             Conv17Args a{};
             a.in = qkv; a.ld_in = 3 * D; a.col0 = 2 * D; a.wT = w.fsmnT; a.C = D; a.out = mem; a.ld_out = D; a.S = T; a.Sp = T;
-            dim3 block(128, 2), grid(1, (T + 2 * 128 - 1) / (2 * 128), B);
-            hipLaunchKernelGGL((conv17_kernel<0, 128, KS>), grid, block, 0, st, a);
-            LAUNCH_CHECK();
+            TRY(pf_launch_fsmn(a, T, B, st));
         }
+        if (pf_attn_small_fits(B, T, T)) {
+            hipLaunchKernelGGL(pf_attn_small_kernel, dim3((T + PF_FA_ROWS - 1) / PF_FA_ROWS, H, B), dim3(256), 0, st, qkv, 3L * D, (long)T * 3 * D, qkv + D, 3L * D,
+                               (long)T * 3 * D, qkv + 2 * D, 3L * D, (long)T * 3 * D, ctx, (long)D, (long)T * D, T, T, 0.08838834764831845f);
+            LAUNCH_CHECK();
+        } else {
         // ---- scores = q k^T / sqrt(dk) per (b, head)
         {
             GemmSeg s = make_seg(qkv, 3 * D, qkv + D, 3 * D, DK, (long)T * 3 * D, (long)T * 3 * D);
@@ -410,6 +492,7 @@ int tdx_pfenc_forward(tdx_pfenc* h, const float* feats, const int* lens_host, in
             g.seg[0].strideB = (long)T * 3 * D; g.seg[0].strideB2 = DK; g.seg[0].kchunk = 0; g.seg[0].ktotal = T;
             if (launch_gemm<false, true, false, false>(g, B * H, EpiCtx{ctx, T}, st) != hipSuccess)
                 return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+        }
         }
         // ---- x = (residual +) ctx W_o + b + memory
         if (launch_h3_split_rows(ctx, D, hp, hs, M, D, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
@@ -816,9 +899,7 @@ int tdx_pfdec_decode(tdx_pfdec* h, const float* emb, int emb_rows, const int* co
         {
             Conv17Args a{};
             a.in = t2; a.ld_in = D; a.col0 = 0; a.wT = w.fsmnT; a.C = D; a.out = memt; a.ld_out = D; a.S = L; a.Sp = L;
-            dim3 block(128, 2), grid(1, (L + 2 * 128 - 1) / (2 * 128), B);
-            hipLaunchKernelGGL((conv17_kernel<0, 128, KS>), grid, block, 0, st, a);
-            LAUNCH_CHECK();
+            TRY(pf_launch_fsmn(a, L, B, st));
         }
         hipLaunchKernelGGL(pf_add_masked_kernel, dim3((unsigned)((M * (D / 4) + 255) / 256)), dim3(256), 0, st, x, memt, M, L, counts);
         LAUNCH_CHECK();
@@ -829,6 +910,11 @@ int tdx_pfdec_decode(tdx_pfdec* h, const float* emb, int emb_rows, const int* co
         else TRY(lin3(hp, hs, w.hq, (int)M, D, D, EpiBiasP{w.bq, q, D}, st));
         if (nsT > 1) TRY(lin3_splitk<RK_BIAS>(encP, encS, w.hkv, (int)MT, 2 * D, D, nsT, slab, w.bkv, kv, 2 * D, nullptr, nullptr, st));
         else TRY(lin3(encP, encS, w.hkv, (int)MT, 2 * D, D, EpiBiasP{w.bkv, kv, 2 * D}, st));
+        if (pf_attn_small_fits(B, L, T)) {
+            hipLaunchKernelGGL(pf_attn_small_kernel, dim3((L + PF_FA_ROWS - 1) / PF_FA_ROWS, H, B), dim3(256), 0, st, q, (long)D, (long)L * D, kv, 2L * D, (long)T * 2 * D,
+                               kv + D, 2L * D, (long)T * 2 * D, ctx, (long)D, (long)L * D, L, T, 0.08838834764831845f);
+            LAUNCH_CHECK();
+        } else {
         {
             GemmSeg s = make_seg(q, D, kv, 2 * D, DK, (long)L * D, (long)T * 2 * D);
             s.zdiv = H; s.strideA2 = DK; s.strideB2 = DK;
@@ -845,6 +931,7 @@ int tdx_pfdec_decode(tdx_pfdec* h, const float* emb, int emb_rows, const int* co
             g.seg[0].strideB = (long)T * 2 * D; g.seg[0].strideB2 = DK; g.seg[0].kchunk = 0; g.seg[0].ktotal = T;
             if (launch_gemm<false, true, false, false>(g, B * H, EpiCtx{ctx, L}, st) != hipSuccess)
                 return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+        }
         }
         if (launch_h3_split_rows(ctx, D, hp, hs, M, D, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
         if (ns512 > 1) TRY(lin3_splitk<RK_BIAS_RES>(hp, hs, w.ho, (int)M, D, D, ns512, slab, w.bo, x, D, nullptr, nullptr, st));

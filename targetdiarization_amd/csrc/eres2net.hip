@@ -111,6 +111,24 @@ struct EpiBiasG {       // v + b, columns < nreal
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
     __device__ void store(int, int m, int n, float v, EpiNone, float c) const { if (n < nreal) out[(long)m * (int)ld + n] = v + c; }
 };
+struct EpiSlabZ {        // split over the taps: partial sums of batch z -> slab[z][m][n]
+    float* slab; long ld; long strideZ;
+    __device__ EpiNone col(int, int) const { return EpiNone{}; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ void store(int z, int m, int n, float v, EpiNone, EpiNone) const { slab[(long)z * strideZ + (long)m * (int)ld + n] = v; }
+};
+// out[m][n] = sum_z slab[z][m][n] (+ bias[n])
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int nz, long MN, int N, const float* __restrict__ bias, float* __restrict__ out) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= MN) return;
+    float4 a = *reinterpret_cast<const float4*>(slab + i);
+    for (int z = 1; z < nz; ++z) {
+        const float4 p = *reinterpret_cast<const float4*>(slab + (long)z * MN + i);
+        a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+    }
+    if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + (int)(i % N)); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    *reinterpret_cast<float4*>(out + i) = a;
+}
 struct EpiChain {       // Res2Net chain: sp = relu20(v+b) -> cat[:, coff+n]; next input sp + spx[i+1] -> spin
     const float* b; float* cat; long ldcat; int coff; int width; int wpad;
     const float* o1; long ldo1; int next_off; float* spin;      // spin == nullptr: no plain-add successor
@@ -266,6 +284,30 @@ int conv_gemm_h3(const unsigned char* Ap, const float* inv_scale, const unsigned
     g.cv_Hin = Hin; g.cv_Win = Win; g.cv_Hout = Hout; g.cv_Wout = Wout; g.cv_stride = stride; g.cv_ntaps = cw.taps; g.cv_cin = cw.cinp;
     g.zero_row = zero_row;
     if (launch_gemm_h3x<false, false, false, false, Epi, 0, true>(g, 1, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    return TDX_OK;
+}
+
+// ... with the 9 taps split over 3 batches of 3 taps (few output rows: e.g. 72 tiles of 576 k-steps for two 8.7 s clips) into
+// slab[3][M][N], then summed
+constexpr long DS_SPLIT_ROWS = 4096;
+constexpr int DS_SPLIT = 3;
+inline int conv_gemm_h3_tapsplit(const unsigned char* Ap, const float* inv_scale, const unsigned char* zero_row, const ConvW& cw, int B, int Hin, int Win,
+                                 int Hout, int Wout, int stride, float* slab, const float* bias, float* out, hipStream_t st) {
+    const long M = (long)B * Hout * Wout;
+    H3Args g{};
+    const int tpb = cw.taps / DS_SPLIT;           // taps per batch
+    g.seg[0] = h3_seg(Ap, inv_scale, 4L * cw.cinp, cw.hp, cw.hs, 4L * cw.taps * cw.cinp, tpb * cw.cinp);
+    g.seg[0].sa_mul = 0;
+    g.seg[0].strideB = 4L * tpb * cw.cinp;
+    g.nseg = 1; g.M = (int)M; g.N = cw.Npad;
+    g.cv_Hin = Hin; g.cv_Win = Win; g.cv_Hout = Hout; g.cv_Wout = Wout; g.cv_stride = stride; g.cv_ntaps = tpb; g.cv_cin = cw.cinp;
+    g.cv_taps_total = cw.taps;
+    g.zero_row = zero_row;
+    if (launch_gemm_h3x<false, false, false, false, EpiSlabZ, 0, true>(g, DS_SPLIT, EpiSlabZ{slab, (long)cw.Npad, M * cw.Npad}, st) != hipSuccess)
+        return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    const long MN = M * cw.Npad;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((MN / 4 + 255) / 256)), dim3(256), 0, st, slab, DS_SPLIT, MN, cw.Npad, bias, out);
+    LAUNCH_CHECK();
     return TDX_OK;
 }
 
@@ -445,7 +487,7 @@ int tdx_eres2net_destroy(tdx_eres2net* h) {
 }
 
 namespace {
-struct WsPlan { size_t P, keep3, o1, spin, tbuf, stats, hx, hcat, hin, total; };
+struct WsPlan { size_t P, keep3, o1, spin, tbuf, stats, hx, hcat, hin, slab, total; };
 inline WsPlan ws_plan(const tdx_eres2net* h, int B, int F) {
     const Dims d = make_dims(F);
     WsPlan w{}; size_t mP = (size_t)B * 80 * F * 64, mo1 = 0, msp = 0, mt = 0, mhx = 0, mhc = 0, mhi = 0;
@@ -466,7 +508,8 @@ inline WsPlan ws_plan(const tdx_eres2net* h, int B, int F) {
     w.stats = al((size_t)B * 40960);
     mhx = std::max(mhx, rows3 * 1024);
     w.hx = al(mhx + 4096); w.hcat = al(mhc + 4096); w.hin = al(mhi + 4096);
-    w.total = 3 * w.P + w.keep3 + 2 * w.o1 + 2 * w.spin + w.tbuf + w.stats + w.hx + w.hcat + w.hin;
+    w.slab = rows4 <= (size_t)DS_SPLIT_ROWS ? al(DS_SPLIT * rows4 * 2048 + 4096) : 0;      // tap-split partial sums of layer3_ds (few rows only)
+    w.total = 3 * w.P + w.keep3 + 2 * w.o1 + 2 * w.spin + w.tbuf + w.stats + w.hx + w.hcat + w.hin + w.slab;
     return w;
 }
 }  // namespace
@@ -511,6 +554,7 @@ int tdx_eres2net_forward(tdx_eres2net* h, const float* feat, int B, int F, float
     unsigned char* hx = (unsigned char*)(stats + wp.stats);
     unsigned char* hcat = hx + wp.hx * sizeof(float);
     unsigned char* hin = hcat + wp.hcat * sizeof(float);
+    float* slab = reinterpret_cast<float*>(hin + wp.hin * sizeof(float));
     const float* inv20 = h->dev + h->consts;            // 2^-10
     const float* inv40 = h->dev + h->consts + 1;        // 2^-9
     const unsigned char* zero_row = (const unsigned char*)(h->dev + h->consts + 64);
@@ -588,7 +632,10 @@ int tdx_eres2net_forward(tdx_eres2net* h, const float* feat, int B, int F, float
     const long M4 = (long)B * d.H[4] * d.W[4];
     if (tdx::launch_h3_split_rows_static(keep3, 1024, hx, (long)B * d.H[3] * d.W[3], 1024, 1024.0f, st) != hipSuccess)
         return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
-    TRY(conv_gemm_h3(hx, inv20, zero_row, h->ds, B, d.H[3], d.W[3], d.H[4], d.W[4], 2, EpiBiasG{nullptr, P[i_ds], 2048, 2048}, st));
+    if (wp.slab && h->ds.taps == 9 && h->ds.Npad == 2048)
+        TRY(conv_gemm_h3_tapsplit(hx, inv20, zero_row, h->ds, B, d.H[3], d.W[3], d.H[4], d.W[4], 2, slab, nullptr, P[i_ds], st));
+    else
+        TRY(conv_gemm_h3(hx, inv20, zero_row, h->ds, B, d.H[3], d.W[3], d.H[4], d.W[4], 2, EpiBiasG{nullptr, P[i_ds], 2048, 2048}, st));
     TRY(run_aff(h, h->fuse34, x, 2048, P[i_ds], 2048, tbuf, P[i_fu], 2048, M4, st));
     hipLaunchKernelGGL(tstp_kernel, dim3(d.H[4], B), dim3(256), 0, st, P[i_fu], stats, d.W[4], 2048, d.H[4]);
     LAUNCH_CHECK();

@@ -109,6 +109,8 @@ struct H3Args {
     // values) reads the planes row of input pixel (b, h*stride+dy, w*stride+dx), (dy,dx) = (tap/3-1, tap%3-1) for 9
     // taps or (0,0) for 1, or `zero_row` (>= 4*cv_cin zero bytes) outside the image; B = [N][ntaps*cv_cin] planes.
     int cv_Hin, cv_Win, cv_Hout, cv_Wout, cv_stride, cv_ntaps, cv_cin;
+    int cv_taps_total;           // > 0: the taps are split over the batches (split-K for few output rows): batch z covers taps
+                                 // [z*cv_ntaps, (z+1)*cv_ntaps) of cv_taps_total; seg[0].strideB = 4*cv_ntaps*cv_cin, K = cv_ntaps*cv_cin
     const unsigned char* zero_row;
     int dbg;                     // diagnostics (env TDX_H3_DEBUG, timing only, wrong results): 1 = no epilogue
     unsigned long long* stamps;  // diagnostics (builds with -DTDX_H3_STAMPS only): 8 x u64 per block, see H3_STAMP
@@ -508,7 +510,9 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
 
     // A_CONV: the A-loader waves' source pointers for one tap (k = 0 of the tap's cv_cin values)
     auto setup_conv = [&](int tap, const unsigned char* (&gp)[4]) {
-        const int dy = g.cv_ntaps == 9 ? tap / 3 - 1 : 0, dx = g.cv_ntaps == 9 ? tap - (tap / 3) * 3 - 1 : 0;
+        const int nt = g.cv_taps_total ? g.cv_taps_total : g.cv_ntaps;
+        if (g.cv_taps_total) tap += z * g.cv_ntaps;
+        const int dy = nt == 9 ? tap / 3 - 1 : 0, dx = nt == 9 ? tap - (tap / 3) * 3 - 1 : 0;
         const int hw = g.cv_Hout * g.cv_Wout;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1182,7 +1186,8 @@ inline hipError_t launch_gemm_h3x(H3Args g, int batches, Epi epi, hipStream_t st
         if ((sg.a_shift || sg.a_period) && (A_TR || A_CONV || (sg.a_period && !sg.a_zero))) return hipErrorInvalidValue;
     }
     if (epi_has_plout<Epi>::value && !PAIRED && g.N % 256) return hipErrorInvalidValue;
-    if (A_CONV && (g.cv_cin < 64 || g.cv_cin % 16 || g.seg[0].K != g.cv_ntaps * g.cv_cin || !g.zero_row || batches != 1)) return hipErrorInvalidValue;
+    if (A_CONV && (g.cv_cin < 64 || g.cv_cin % 16 || g.seg[0].K != g.cv_ntaps * g.cv_cin || !g.zero_row ||
+                   batches != (g.cv_taps_total ? g.cv_taps_total / g.cv_ntaps : 1) || (g.cv_taps_total && g.cv_taps_total % g.cv_ntaps))) return hipErrorInvalidValue;
     static const int dbg = [] { const char* e = getenv("TDX_H3_DEBUG"); return e ? atoi(e) : 0; }();
     g.dbg = dbg;
     hipLaunchKernelGGL((gemm_h3_kernel<A_TR, B_TR, PAIRED, TWOSEG, Epi, VARIANT, A_CONV>), grid, dim3(H3_THREADS), H3_LDS + H3_LDS_EXTRA, st, g, epi);

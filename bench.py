@@ -522,7 +522,7 @@ def main():
     ap.add_argument("--workload", default=None, choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"],
                     help="default: cfg4 (BASELINE configs[3], the full pipe on 1800 s) at one GPU, cfg5 (BASELINE configs[4], the "
                          "1000-utterance job, strong scaling) at more; cfg2 = MossFormer2 only; cfg3 = 600 s without the ASR encoder")
-    ap.add_argument("--windows-per-launch", type=int, default=30, help="10 s windows per MossFormer2 launch sequence")
+    ap.add_argument("--windows-per-launch", type=int, default=90, help="10 s windows per MossFormer2 launch sequence (90 = 1.8 M token rows: the launches get larger, not more — DESIGN.md §5)")
     ap.add_argument("--utterances", type=int, default=1000, help="cfg5: utterances in the job")
     ap.add_argument("--utterances-per-step", type=int, default=200, help="cfg5: utterances per step (global batch, all ranks together)")
     ap.add_argument("--batch", type=int, default=32, help="cfg2: windows per GPU")

@@ -174,3 +174,20 @@ def test_config5_world2_bookkeeping_on_one_device(hp24, monkeypatch):
         assert rel(res[r]["scores"].cpu().numpy(), ref["scores"].cpu().numpy()) < 1e-5
         for j, i in enumerate(pipeline.shard_indices(n_total, r, world)):
             assert rel(res[r]["streams"][j].cpu().numpy(), ref["streams"][i].cpu().numpy()) < 1e-5
+
+
+def test_large_launch_equals_smaller_launches(sep24):
+    """bench.py's default runs 90 windows of 10 s per launch sequence (1.8 M token rows; > 2^31 elements in the to_hidden output
+    already at 47 windows): 60 windows as ONE launch sequence against two of 30 — windows are independent, only the chunking of
+    the split-K lin_k^T[v|u] launch depends on the batch (fp32 accumulation order)."""
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(60, 160000, generator=g) * 0.1).cuda()
+    big = sep24(x)
+    two = torch.cat([sep24(x[:30]), sep24(x[30:])])
+    assert bool(torch.isfinite(big).all())
+    d, m = float((big - two).abs().max()), float(two.abs().max())
+    assert d <= 1e-5 * m, (d, m)
+    # first and last window against a launch of their own
+    for i in (0, 59):
+        one = sep24(x[i:i + 1])
+        assert float((big[i:i + 1] - one).abs().max()) <= 1e-5 * m

@@ -176,7 +176,9 @@ def pipe_bench(args):
     asr_sd = None
     if with_asr:                                  # 50-layer SANM encoder + CIF predictor + 16-layer NAR decoder (vocabulary 8404)
         asr_sd = dict(recipe_paraformer_state_dict(0, 50)); asr_sd.update(recipe_paraformer_decoder_state_dict(0, 16))
-    hp = HotPath(sep_sd, spk_sd, asr_sd, cuda_device=local_rank, windows_per_launch=args.windows_per_launch)
+    hp = HotPath(sep_sd, spk_sd, asr_sd, cuda_device=local_rank, windows_per_launch=args.windows_per_launch,
+                 asr_rows_per_launch=args.asr_rows_per_launch)
+    hp.spk.max_batch_frames = args.embed_frames_per_launch
     target = torch.from_numpy(np.random.default_rng(5).standard_normal(192).astype(np.float32)).to(dev)
 
     if wl in ("cfg3", "cfg4"):
@@ -522,6 +524,8 @@ def main():
     ap.add_argument("--workload", default=None, choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"],
                     help="default: cfg4 (BASELINE configs[3], the full pipe on 1800 s) at one GPU, cfg5 (BASELINE configs[4], the "
                          "1000-utterance job, strong scaling) at more; cfg2 = MossFormer2 only; cfg3 = 600 s without the ASR encoder")
+    ap.add_argument("--asr-rows-per-launch", type=int, default=65536, help="LFR frames per Paraformer launch sequence")
+    ap.add_argument("--embed-frames-per-launch", type=int, default=160000, help="fbank frames per ERes2NetV2 launch sequence")
     ap.add_argument("--windows-per-launch", type=int, default=90, help="10 s windows per MossFormer2 launch sequence (90 = 1.8 M token rows: the launches get larger, not more — DESIGN.md §5)")
     ap.add_argument("--utterances", type=int, default=1000, help="cfg5: utterances in the job")
     ap.add_argument("--utterances-per-step", type=int, default=200, help="cfg5: utterances per step (global batch, all ranks together)")

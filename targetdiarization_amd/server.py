@@ -4,8 +4,9 @@ sampling_rate, is_single, output_target_audio) and `WS /diarization/stream` (con
 
 Differences, all on the host side: uploads are decoded with the stdlib `wave` module (16-bit PCM; the reference hands the temp file
 to audioread) and resampled on the device; the multipart body is parsed with the stdlib `email` parser (python-multipart is not a
-dependency); the streaming endpoint buffers `max_buffer_duration` seconds (default 10) per inference instead of the reference's
-silero-VAD router (TargetDiarizationStream.py:81-171: third-party VAD) — a `vad` plug-in of the model still trims the target clip.
+dependency); the streaming endpoint drives `model.infer_stream` (target_diarization_stream.TargetDiarizationStream: the reference's
+VAD-buffer router with plug-in detectors) in a worker thread like main.py:330-400; a model without `infer_stream` gets fixed
+`max_buffer_duration` buffers (default 10 s) through `infer()`.
 
     app = create_app(model)          # model: targetdiarization_amd.target_diarization.TargetDiarization (or None: 500 on infer)
     uvicorn.run(app, host="0.0.0.0", port=8000)
@@ -145,6 +146,57 @@ def create_app(model=None, max_buffer_duration: float = 10.0):
                 if msg.get("type") == "target_audio":
                     target = np.frombuffer(base64.b64decode(msg.get("data")), dtype=np.int16).astype(np.float32) / 32767.0
             await websocket.send_json({"type": "config_ack", "data": {"config": config, "target_file_loaded": target is not None}})
+            if hasattr(app.state.model, "infer_stream"):
+                # the reference's arrangement (main.py:330-400): the session's generator runs in a worker thread, fed through a queue
+                import asyncio
+                import queue
+                import threading
+                inq, outq, loop = queue.Queue(), asyncio.Queue(), asyncio.get_running_loop()
+
+                def chunks():
+                    while True:
+                        c = inq.get()
+                        if c is None:
+                            return
+                        yield c
+
+                def worker():
+                    try:
+                        for spk, res, _ in app.state.model.infer_stream(chunks(), target_file=target, sampling_rate=16000,
+                                                                        is_single=bool(config.get("is_single", False)), output_target_audio=False):
+                            loop.call_soon_threadsafe(outq.put_nowait, ("seg", spk, res))
+                    except Exception as e:
+                        loop.call_soon_threadsafe(outq.put_nowait, ("err", str(e), None))
+                    loop.call_soon_threadsafe(outq.put_nowait, ("done", None, None))
+
+                threading.Thread(target=worker, daemon=True).start()
+
+                async def feed():
+                    try:
+                        while True:
+                            msg = await websocket.receive_json()
+                            if msg.get("type") == "audio_chunk":
+                                inq.put(np.frombuffer(base64.b64decode(msg.get("data")), dtype=np.int16).astype(np.float32) / 32767.0)
+                            elif msg.get("type") == "end":
+                                break
+                    finally:
+                        inq.put(None)
+
+                feeder = asyncio.ensure_future(feed())
+                while True:
+                    kind, a, res = await outq.get()
+                    if kind == "seg":
+                        for seg in res:
+                            await websocket.send_json({"type": "segment_result", "data": {"target_speaker_id": a, "segment": {
+                                "speaker": seg["speaker"], "speaker_type": format_speaker_info(seg["speaker"], a),
+                                "timerange": [round(float(seg["timerange"][0]), 3), round(float(seg["timerange"][1]), 3)], "text": seg["text"], "type": seg["type"]}}})
+                    elif kind == "err":
+                        await websocket.send_json({"type": "error", "message": f"Processing error: {a}"})
+                    else:
+                        break
+                await feeder
+                await websocket.send_json({"type": "status", "message": "completed"})
+                return
             buf, offset = [], 0.0
             limit = int(float(config.get("max_buffer_duration", max_buffer_duration)) * 16000)
 

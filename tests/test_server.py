@@ -93,3 +93,31 @@ def test_helpers():
     assert format_speaker_info("2", "2") == "target" and format_speaker_info("-1", "2") == "uncertain" and format_speaker_info("1", "2") == "other"
     d = build_response_data("", [], None, True)
     assert d["statistics"]["total_duration"] == 0.0 and d["results"] == [] and "target_audio_base64" not in d
+
+
+def test_websocket_drives_a_streaming_session():
+    """a model with infer_stream (TargetDiarizationStream) is fed chunk by chunk from a worker thread; results are forwarded as they come"""
+    class StreamModel(FakeModel):
+        def infer_stream(self, gen, target_file=None, sampling_rate=16000, is_single=False, output_target_audio=False):
+            t = 0.0
+            for i, c in enumerate(gen):
+                d = c.shape[0] / 16000.0
+                yield "1", [{"speaker": "1" if i % 2 == 0 else "0", "timerange": [t, t + d], "text": f"seg{i}", "type": "single"}], None
+                t += d
+    c = TestClient(create_app(StreamModel()))
+    chunk = base64.b64encode((np.arange(8000) % 100).astype(np.int16).tobytes()).decode()
+    with c.websocket_connect("/diarization/stream") as ws:
+        ws.send_json({"type": "config", "data": {}})
+        assert ws.receive_json()["type"] == "config_ack"
+        for _ in range(3):
+            ws.send_json({"type": "audio_chunk", "data": chunk})
+        ws.send_json({"type": "end"})
+        msgs = []
+        while True:
+            m = ws.receive_json()
+            msgs.append(m)
+            if m["type"] == "status":
+                break
+    segs = [m["data"]["segment"] for m in msgs if m["type"] == "segment_result"]
+    assert [s_["text"] for s_ in segs] == ["seg0", "seg1", "seg2"] and [s_["speaker_type"] for s_ in segs] == ["target", "other", "target"]
+    assert segs[2]["timerange"] == [1.0, 1.5]

@@ -573,13 +573,13 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
             if (sg0.segk && tid < 256) {          // factors of the segment boundaries: units of segment j -> units of segment j+1
                 const float* sab = sg0.sa + (long)(z / sg0.zdiv) * sg0.strideSA + (long)zz2 * sg0.strideSA2 + (long)min(m0 + tid, g.M - 1) * sg0.sa_mul;
                 float* rft = reinterpret_cast<float*>(lds + H3_LDS + 4096);
-                const int nb = sg0.K / sg0.segk - 1;
-                float prev = sab[0];
-                for (int j = 0; j < nb; ++j) {
-                    const float nxt = sab[(long)(j + 1) * sg0.strideSeg];
-                    rft[j * 256 + tid] = prev / nxt;
-                    prev = nxt;
-                }
+                const int nb = sg0.K / sg0.segk - 1;          // (<= 7: host-checked)
+                float sc[8];                                  // all segment scales requested at once: a load -> divide -> store chain per
+#pragma unroll                                                // boundary cost the to_out tile 4-5 us of exposed latency
+                for (int j = 0; j < 8; ++j) sc[j] = sab[(long)min(j, nb) * sg0.strideSeg];
+#pragma unroll
+                for (int j = 0; j < 7; ++j)
+                    if (j < nb) rft[j * 256 + tid] = sc[j] / sc[j + 1];
             }
         }
 

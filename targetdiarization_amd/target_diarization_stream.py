@@ -25,23 +25,19 @@ class TargetDiarizationStream(TargetDiarization):
     def __init__(self, is_vad_buffer: bool = True, use_asr_prompt: bool = False, similarity_threshold: float = 0.4, vad_min_silence: float = 0.3,
                  max_buffer_duration: float = 30.0, loudness_diff_threshold: float = 12.0, *args, stream_vad: Optional[Callable] = None, **kwargs):
         super().__init__(*args, **kwargs)
-        self.is_vad_buffer = is_vad_buffer
-        self.use_asr_prompt = use_asr_prompt
-        self.similarity_threshold = similarity_threshold
-        self.max_buffer_duration = max_buffer_duration
-        self.vad_min_silence = vad_min_silence
-        self.loudness_diff_threshold = loudness_diff_threshold
-        self.stream_vad = stream_vad or _whole_clip_vad
-        self.current_time = 0.0
-        self.target_embedding = None
-        self.prev_asr_text = ""
-        self.vad_buffer = []
-        self.current_buffer_duration = 0.0
-        self.system_loudness_diff = 0.0
+        # configuration (the reference's attribute names: callers read and tune them between sessions)
+        for name, value in (("is_vad_buffer", is_vad_buffer), ("use_asr_prompt", use_asr_prompt), ("similarity_threshold", similarity_threshold),
+                            ("max_buffer_duration", max_buffer_duration), ("vad_min_silence", vad_min_silence),
+                            ("loudness_diff_threshold", loudness_diff_threshold), ("stream_vad", stream_vad or _whole_clip_vad)):
+            setattr(self, name, value)
+        # session state
+        self.vad_buffer, self.current_buffer_duration = [], 0.0
+        self.current_time, self.prev_asr_text = 0.0, ""
+        self.target_embedding, self.system_loudness_diff = None, 0.0
 
     # ---- helpers --------------------------------------------------------------------------------
     def clear_vad_buffer(self):
-        self.vad_buffer.clear()
+        del self.vad_buffer[:]
         self.current_buffer_duration = 0.0
 
     def meter_loudness(self, audio: np.ndarray) -> float:
@@ -101,24 +97,22 @@ class TargetDiarizationStream(TargetDiarization):
 
     # ---- VAD buffer router (:81-110) ------------------------------------------------------------
     def process_vad_chunk(self, pcm_chunk: np.ndarray, is_single: bool):
-        if pcm_chunk is None or pcm_chunk.shape[0] == 0:
+        if pcm_chunk is None or not pcm_chunk.shape[0]:
             return
-        is_silence = False
-        if self.system_loudness_diff != 0.0:
-            if self.meter_loudness(pcm_chunk) < -23.0 + self.system_loudness_diff - self.loudness_diff_threshold:
-                is_silence = True
-                pcm_chunk = np.full_like(pcm_chunk, fill_value=0.00001, dtype=np.float32)
+        # loudness gate (armed once a target level is known): a chunk far below it enters the buffer as near-silence
+        gated = self.system_loudness_diff != 0.0 and \
+            self.meter_loudness(pcm_chunk) < -23.0 + self.system_loudness_diff - self.loudness_diff_threshold
+        if gated:
+            pcm_chunk = np.full_like(pcm_chunk, fill_value=0.00001, dtype=np.float32)
         self.vad_buffer.append(pcm_chunk)
         self.current_buffer_duration += round(pcm_chunk.shape[0] / 16000, 3)
-        if not self.is_vad_buffer:
-            if is_silence:
-                return
-            yield from self.process_single_chunk(self.vad_buffer[-1], is_single)
-            self.clear_vad_buffer()
+        if not self.is_vad_buffer:              # no buffering: every audible chunk on its own (a gated one stays in the buffer, :95-96)
+            release = None if gated else self.vad_buffer[-1]
+        else:
+            release = None if self.should_wait_for_next_chunk(is_silence=gated) else np.concatenate(self.vad_buffer)
+        if release is None:
             return
-        if self.should_wait_for_next_chunk(is_silence=is_silence):
-            return
-        yield from self.process_single_chunk(np.concatenate(self.vad_buffer), is_single)
+        yield from self.process_single_chunk(release, is_single)
         self.clear_vad_buffer()
 
     # ---- the five rules (:113-171) --------------------------------------------------------------

@@ -345,6 +345,8 @@ struct LayerW {
 
 }  // namespace
 
+constexpr long FORK_ROWS = 100000;      // token rows up to which a FLASH layer forks its q/k-head branch onto the side stream
+
 struct tdx_mf2 {
     int device;
     int L;
@@ -361,6 +363,10 @@ struct tdx_mf2 {
     // the forward's stream, read back by tdx_mf2_profile_collect after the caller synchronised.
     std::vector<hipEvent_t> ev0, ev1;
     size_t ev_used;
+    // small forwards (one window per call): the q/k-head branch of a FLASH layer (conv17<3> -> similarity GEMM) runs on this side
+    // stream next to the v|u branch (conv17<4> -> lin_k^T[v|u]); fork / join by events, so the pair is capturable in a HIP graph
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_heads = nullptr, ev_sim = nullptr;
 };
 
 namespace {
@@ -514,7 +520,11 @@ inline bool use_h3a() {
 int attention_core_h3(const unsigned char* qkP, const float* qks, const unsigned char* vuP, const float* vu, const float* st,
                       int B, int S, int E, int splits, int kchunk, float* Abuf, unsigned char* AbufP, float* Asc, float* slab, float* kvu,
                       unsigned char* KvuP, float* kvus, float* o, float* att_v, float* att_u, hipStream_t st_,
-                      unsigned char* oP = nullptr, float* os = nullptr, float* oss = nullptr) {
+                      unsigned char* oP = nullptr, float* os = nullptr, float* oss = nullptr,
+                      hipStream_t side = nullptr, hipEvent_t ev_heads = nullptr, hipEvent_t ev_sim = nullptr) {
+    // side != nullptr: the similarity GEMM runs on `side` (which already holds the conv17<3> that wrote the heads; `ev_heads` was
+    // recorded behind it), next to lin_k^T[v|u] on st_; st_ waits for the heads before it reads lin_k and for the similarity
+    // (`ev_sim`) before the attention launch
     const int G = (S + 255) / 256, Sp = G * 256;
     const long hs = (long)B * Sp;                 // rows per head
     const unsigned char *quad_q = qkP, *lin_q = qkP + hs * 512, *quad_k = qkP + 2 * hs * 512, *lin_k = qkP + 3 * hs * 512;
@@ -525,7 +535,11 @@ int attention_core_h3(const unsigned char* qkP, const float* qks, const unsigned
         g.seg[0].strideA = 256L * 512; g.seg[0].strideB = 256L * 512; g.seg[0].strideSA = 256; g.seg[0].strideSB = 256;
         g.nseg = 1; g.M = 256; g.N = 256;
         EpiQuadSimPl e{AbufP, Asc, G, S, 1.0f / 256.0f};         // (planes straight from the epilogue: no fp32 similarity, no split pass)
-        if (tdx::launch_gemm_h3x<false, false, false, false>(g, B * G, e, st_) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+        if (tdx::launch_gemm_h3x<false, false, false, false>(g, B * G, e, side ? side : st_) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+        if (side) {
+            if (hipEventRecord(ev_sim, side) != hipSuccess || hipStreamWaitEvent(st_, ev_heads, 0) != hipSuccess)
+                return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+        }
     }
     {   // Kvu[b][d][ch] = (1/S) sum_t lin_k[t][d] vu[t][ch], split over token chunks         mossformer_block.py:286,289
         // M = 128 (d): the 128 rows of waves 4-7 do not exist and those waves only feed the ring; lin_k is the A operand — once
@@ -568,6 +582,7 @@ int attention_core_h3(const unsigned char* qkP, const float* qks, const unsigned
         g.seg[1].strideB = (long)QK * 4 * 2 * E; g.seg[1].strideB2 = 0;
         g.seg[1].strideSB = 1; g.seg[1].strideSB2 = 0;
         g.nseg = 2; g.M = 256; g.N = E; g.pair_off = E;
+        if (side && hipStreamWaitEvent(st_, ev_sim, 0) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
         {   // (diagnostic, timing only, wrong results: TDX_H3_DEBUG & 2 = every group reads the first group's v|u rows — an L2-resident B operand)
             static const int dbg = [] { const char* e = getenv("TDX_H3_DEBUG"); return e ? atoi(e) : 0; }();
             if (dbg & 2) { g.seg[0].strideB = 0; g.seg[0].strideB2 = 0; }
@@ -617,11 +632,11 @@ int ddn_core(const float* p, int B, int S, const float* w1T, const float* w2T, c
     const int nchunk1 = (S + ts - 1) / ts, nchunk2 = 2 * ((S + 2 * ts - 1) / (2 * ts));
     hipLaunchKernelGGL(ddn_conv1_kernel, dim3(nchunk1, B), dim3(256), 0, st, p, w1T, c1, part, S, nchunk1, ts);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(in_finalize_kernel, dim3(B, 4), dim3(256), 0, st, part, stat1, nchunk1, S);
+    hipLaunchKernelGGL(in_finalize_kernel, dim3(B, 16), dim3(256), 0, st, part, stat1, nchunk1, S);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(ddn_conv2_kernel, dim3(nchunk2, B), dim3(256), 0, st, c1, p, stat1, ing, inb, pre, w2T, c2, part, S, nchunk2, ts);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(in_finalize_kernel, dim3(B, 4), dim3(256), 0, st, part, stat2, nchunk2, S);
+    hipLaunchKernelGGL(in_finalize_kernel, dim3(B, 16), dim3(256), 0, st, part, stat2, nchunk2, S);
     LAUNCH_CHECK();
     return TDX_OK;
 }
@@ -919,6 +934,13 @@ int tdx_mf2_create(const tdx_mf2_config* cfg, const void* blob, size_t blob_byte
         e = hipDeviceSynchronize();
         if (e != hipSuccess) { hipFree(h->dev_planes); hipFree(dev); delete h; return tdx::fail_hip(e, __FILE__, __LINE__); }
     }
+    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_heads, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_sim, hipEventDisableTiming) != hipSuccess) {
+        tdx_mf2_destroy(h);
+        return tdx::fail(TDX_E_HIP, "tdx_mf2_create: side stream / events");
+    }
     *out = h;
     return TDX_OK;
 }
@@ -930,6 +952,10 @@ int tdx_mf2_destroy(tdx_mf2* h) {
     if (h->dev_static) hipFree(h->dev_static);
     for (auto e : h->ev0) hipEventDestroy(e);
     for (auto e : h->ev1) hipEventDestroy(e);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_heads) hipEventDestroy(h->ev_heads);
+    if (h->ev_sim) hipEventDestroy(h->ev_sim);
+    if (h->side) hipStreamDestroy(h->side);
     delete h;
     return TDX_OK;
 }
@@ -1049,6 +1075,11 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
             if (launch_linear_x3<true>(g, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
             if (prof) { hipEventRecord(h->ev1[h->ev_used], st); h->ev_used++; }
         }
+        // small forwards: the q/k-head branch (conv17<3> -> similarity) on the side stream, next to the v|u branch
+        const bool fork = h->side && M <= FORK_ROWS;
+        hipStream_t sq = fork ? h->side : st;
+        if (fork && (hipEventRecord(h->ev_fork, st) != hipSuccess || hipStreamWaitEvent(h->side, h->ev_fork, 0) != hipSuccess))
+            return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
         {
             Conv17Args a{};
             a.in = hid; a.ld_in = HQ; a.col0 = 0; a.wT = w.cw_h; a.C = HID; a.out = nullptr; a.ld_out = HID; a.S = S; a.Sp = Sp;
@@ -1058,10 +1089,11 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
             q.in = hid; q.ld_in = HQ; q.col0 = HID; q.wT = w.cw_qk; q.C = QK; q.S = S; q.Sp = Sp; q.gamma = w.gamma; q.beta = w.beta;
             q.rot_cos = rc; q.rot_sin = rsn; q.head_stride = (long)B * Sp * QK;
             q.hp = (unsigned char*)qk4; q.hs = qks; q.sv = w.sv_lk; q.silu_in = 1;
-            TRY(launch_conv17<3>(q, B, st));          // the four heads as planes
+            TRY(launch_conv17<3>(q, B, sq));          // the four heads as planes
+            if (fork && hipEventRecord(h->ev_heads, h->side) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
         }
         TRY(attention_core_h3((const unsigned char*)qk4, qks, vuP, nullptr, w.st, B, S, 1024, P.splits, P.kchunk, Abuf, AbufP, Asc, slab, kvu, KvuP,
-                              kvus, nullptr, nullptr, nullptr, st, oP, os, oss));
+                              kvus, nullptr, nullptr, nullptr, st, oP, os, oss, fork ? h->side : nullptr, h->ev_heads, h->ev_sim));
         {   // to_out: A = the planes of o with one row scale per 128-channel segment; ScaleNorm from the segments' sums of squares
             tdx::H3Args g{};
             g.seg[0] = tdx::h3_seg(oP, os, 4L * 1024, w.hWo.p, w.hWo.s, 4L * 1024, 1024);

@@ -273,24 +273,25 @@ __global__ __launch_bounds__(256) void ddn_conv1_kernel(const float* __restrict_
     part[(((long)b * nchunk + blockIdx.x) * 256 + ch) * 2 + 1] = sq;
 }
 
-// stat[b][c] = (mean, rstd) with biased variance over S tokens, eps 1e-5 (InstanceNorm2d).  grid (B, 4): a block owns 64 channels,
-// its four waves walk the chunk partials in parallel (a one-window call has ~270 short chunks and B = 1: one block with one
-// thread per channel took 20-50 us, 48 times per forward)
+// stat[b][c] = (mean, rstd) with biased variance over S tokens, eps 1e-5 (InstanceNorm2d).  grid (B, 16): a block owns 16 channels,
+// 16 thread groups walk the chunk partials in parallel (a one-window call has ~270 short chunks and B = 1: one thread per channel
+// took 20-50 us, four groups per channel 22 us — 48 times per forward)
 __global__ __launch_bounds__(256) void in_finalize_kernel(const double* __restrict__ part, float* __restrict__ stat,
                                                            int nchunk, int S) {
-    __shared__ double red[4][64][2];
-    const int b = blockIdx.x, ch = blockIdx.y * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    __shared__ double red[16][16][2];
+    const int b = blockIdx.x, cl = threadIdx.x & 15, g = threadIdx.x >> 4, ch = blockIdx.y * 16 + cl;
     double s = 0, q = 0;
-    for (int i = g; i < nchunk; i += 4) {
-        s += part[(((long)b * nchunk + i) * 256 + ch) * 2];
-        q += part[(((long)b * nchunk + i) * 256 + ch) * 2 + 1];
+#pragma unroll 4
+    for (int i = g; i < nchunk; i += 16) {
+        const double2 v = *reinterpret_cast<const double2*>(part + (((long)b * nchunk + i) * 256 + ch) * 2);
+        s += v.x; q += v.y;
     }
-    red[g][threadIdx.x & 63][0] = s; red[g][threadIdx.x & 63][1] = q;
+    red[g][cl][0] = s; red[g][cl][1] = q;
     __syncthreads();
     if (g == 0) {
-        const int l = threadIdx.x;
-        s = (red[0][l][0] + red[1][l][0]) + (red[2][l][0] + red[3][l][0]);
-        q = (red[0][l][1] + red[1][l][1]) + (red[2][l][1] + red[3][l][1]);
+        s = 0; q = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { s += red[k][cl][0]; q += red[k][cl][1]; }
         const double mean = s / S;
         double var = q / S - mean * mean;
         if (var < 0) var = 0;

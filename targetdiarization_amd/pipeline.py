@@ -18,6 +18,8 @@ rank's [n_i*2,192] block, zero-padded to the largest n_i).
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -73,6 +75,7 @@ class HotPath:
         self.asr_segment = asr_segment
         self.windows_per_launch = windows_per_launch
         self.asr_rows_per_launch = asr_rows_per_launch
+        self.overlap_seconds = float(os.environ.get("TDX_OVERLAP_SECONDS", "1e9"))     # run(): stage overlap on side streams up to this much audio per call
 
     def _dev(self, a):
         """host array or tensor -> 1-D float32 device tensor (the one H2D of the path)"""
@@ -166,11 +169,12 @@ class HotPath:
         to_host=False leaves every result on the device (the benchmark's resident-in-HBM boundary).
         target_clip: the target speaker's sample as a waveform instead of `target_embedding` (TargetDiarization.infer has both clips
         at hand, :98-121): its embedding is computed on a side stream WHILE the mix is separated.
-        Small inputs (the reference's one-clip-per-call pattern: every kernel is far from filling the GPU) overlap the independent
-        stages on HIP streams: target embedding || separation, then speaker embeddings || Paraformer."""
+        The independent stages overlap on HIP streams: target embedding || separation, then speaker embeddings || Paraformer
+        (one clip per call: −8 ms of 50; 1800 s per call: −1 %, the stages fill each other's tails; `overlap_seconds` /
+        env TDX_OVERLAP_SECONDS bounds the audio per call up to which this is done, default: always)."""
         n_total = n_total if n_total is not None else len(utts)
         main = torch.cuda.current_stream(self.device)
-        overlap = sum(int(u.shape[0]) for u in utts) <= 60 * 16000
+        overlap = sum(int(u.shape[0]) for u in utts) <= self.overlap_seconds * 16000
         side0 = None
         if target_clip is not None and self.spk is not None:
             tclip = self._dev(target_clip)

@@ -49,6 +49,14 @@ class TargetASR:
             wav_file = [wav_file]
         return self.embedding[embedding_model].get_speaker_embedding(wav_file)
 
+    # TargetASR.py:491-505
+    def is_same_person(self, existed_embeddings, target_embedding: np.ndarray, threshold: float = 0.4, verbose_result: bool = False):
+        """cosine score of the MEAN of the known embeddings against the candidate, compared with the threshold"""
+        known = [existed_embeddings] if isinstance(existed_embeddings, np.ndarray) else list(existed_embeddings)
+        score = self.cosine_similarity(np.mean(known, axis=0), target_embedding)
+        same = bool(score >= threshold)
+        return {"is_same": same, "score": round(score, 3)} if verbose_result else same
+
     def get_speaker_embeddings(self, wavs, embedding_model: str = "eres2netv2_large") -> np.ndarray:
         """MI355X addition: one bucketed launch sequence for a list of clips (hot loops A/C)."""
         return self.embedding[embedding_model].get_speaker_embeddings(wavs)

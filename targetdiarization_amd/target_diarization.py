@@ -295,13 +295,29 @@ class TargetDiarization:
         return result, (np.concatenate(parts, axis=0) if parts else None)
 
     # ---- main entry (:98-163) ------------------------------------------------------------------
+    @staticmethod
+    def read_audio(src, sampling_rate: int = 16000):
+        """AudioProcessor.read_audio (:432-470) for the formats the stdlib decodes: a numpy array passes through with the caller's
+        rate; a path / bytes / file object must be PCM16 .wav (the reference hands everything else to audioread / ffmpeg)"""
+        if isinstance(src, np.ndarray):
+            return src, sampling_rate
+        import io
+        import wave
+        f = io.BytesIO(src) if isinstance(src, (bytes, bytearray)) else src
+        with wave.open(f, "rb") as w:
+            if w.getsampwidth() != 2:
+                raise ValueError("read_audio(): only 16-bit PCM .wav is decoded here")
+            x = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+            ch, sr = w.getnchannels(), w.getframerate()
+        return (x.reshape(-1, ch) if ch > 1 else x), sr
+
     def infer(self, wav_file, target_file=None, sampling_rate: int = 16000, is_single: bool = False, output_target_audio: bool = True):
-        if isinstance(wav_file, (str, bytes)) or sampling_rate != 16000:
-            raise ValueError("infer(): pass 16 kHz mono numpy audio (file decoding / resampling are outside the MI355X hot path)")
-        audio = self.audio_preprocess(wav_file)
+        wav, sr = self.read_audio(wav_file, sampling_rate)
+        audio = self.audio_preprocess(wav, sr)
         target_embedding = None
         if target_file is not None:
-            tgt = self.audio_preprocess(target_file)
+            tw, tsr = self.read_audio(target_file, sampling_rate)
+            tgt = self.audio_preprocess(tw, tsr)
             v = self.vad(tgt)
             if v:
                 tgt = self.split_audio_by_time(tgt, v[0][0], v[-1][1])

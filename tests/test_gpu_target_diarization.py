@@ -151,3 +151,18 @@ def test_streaming_session_on_the_device(gold, sd2):
         assert set(r) >= {"speaker", "timerange", "text", "type"} and r["speaker"] in ("0", "1") and r["type"] == "single" and r["text"]
         assert r["timerange"][0] >= t_prev
         t_prev = r["timerange"][0]
+
+
+def test_infer_accepts_wav_paths_and_other_rates(gold, sd2):
+    """the reference's infer() takes paths / file objects at any rate (TargetDiarization.py:98-121): a .wav path gives the result
+    of the array call, and an 8 kHz copy goes through the device resampler"""
+    from targetdiarization_amd.target_diarization import TargetDiarization
+    from targetdiarization_amd.weights import recipe_eres2netv2_state_dict
+    td = TargetDiarization(cuda_device=0, sep_state_dict=sd2, spk_state_dict=recipe_eres2netv2_state_dict(0))
+    mix = _load(gold, "chat_mix.wav")
+    spk_a, res_a, aud_a = td.infer(mix, None)
+    spk_p, res_p, aud_p = td.infer(os.path.join(gold, "chat_mix.wav"), None)
+    assert spk_a == spk_p and [r["timerange"] for r in res_a] == [r["timerange"] for r in res_p]
+    assert np.abs(aud_a - aud_p).max() < 1e-4 * max(np.abs(aud_a).max(), 1e-9) + 1e-6
+    spk_8, res_8, aud_8 = td.infer(mix[::2].copy(), None, sampling_rate=8000)
+    assert abs(res_8[-1]["timerange"][1] - res_a[-1]["timerange"][1]) < 0.01 and aud_8.shape[0] == aud_a.shape[0]

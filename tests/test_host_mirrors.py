@@ -36,3 +36,28 @@ def test_target_asr_without_models_raises_keyerror_like_reference():
     t = TargetASR(cuda_device=0)
     with pytest.raises(KeyError):
         t.get_speaker_embedding(np.zeros(16000, dtype=np.float32))
+
+
+def test_read_audio_and_is_same_person():
+    """host pieces of the drop-in surface: TargetDiarization.read_audio (PCM16 .wav by path / bytes / file object, arrays pass
+    through) and TargetASR.is_same_person (mean of the known embeddings, threshold, verbose form: TargetASR.py:491-505)"""
+    import io
+    import os
+    from targetdiarization_amd.target_asr import TargetASR
+    from targetdiarization_amd.target_diarization import TargetDiarization
+    path = os.path.join(os.path.dirname(__file__), "golden", "chat_mix.wav")
+    x, sr = TargetDiarization.read_audio(path)
+    assert sr == 16000 and x.dtype == np.int16 and x.shape == (138634,)
+    raw = open(path, "rb").read()
+    for src in (raw, io.BytesIO(raw)):
+        y, sr2 = TargetDiarization.read_audio(src)
+        assert sr2 == 16000 and np.array_equal(x, y)
+    arr = np.zeros(10, np.float32)
+    assert TargetDiarization.read_audio(arr, 8000) == (arr, 8000) or TargetDiarization.read_audio(arr, 8000)[1] == 8000
+    t = TargetASR()                                   # no models: the embedding arithmetic is host-side
+    a, b = np.array([1.0, 0.0, 0.0]), np.array([0.0, 1.0, 0.0])
+    assert t.is_same_person(a, a) is True and t.is_same_person(a, b) is False
+    assert t.is_same_person([a, b], a, threshold=0.7) is True          # mean (0.5, 0.5, 0) vs a: cos = 0.707
+    assert t.is_same_person([a, b], a, threshold=0.71) is False
+    assert t.is_same_person(a, b, verbose_result=True) == {"is_same": False, "score": 0.0}
+    assert t.is_same_person(np.zeros(3), b) is True                     # an all-zero embedding scores 1.0 (:145-146)

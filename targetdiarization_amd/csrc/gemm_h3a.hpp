@@ -25,7 +25,10 @@ constexpr int H3A_B = 16 * 1024;               // 16 KB: 16 k rows x [v block: h
 constexpr int H3A_STAGE = H3A_A + H3A_B;       // 24 KB
 constexpr int H3A_NBUF = 3;
 constexpr int H3A_LDS = H3A_NBUF * H3A_STAGE;  // 72 KB
-constexpr int H3A_EXTRA = 2048;                // TWOSEG row factors 512 B | row scales 512 B | row() values 1 KB
+constexpr int H3A_EXTRA = 2048;
+#ifndef H3A_PIN
+#define H3A_PIN 0      // 1: sched_barrier after every MFMA group (reads interleaved as written): 28.6 vs 27.1 us per k loop — no better
+#endif                // TWOSEG row factors 512 B | row scales 512 B | row() values 1 KB
 
 template <bool TWOSEG, class Epi>
 __global__ __launch_bounds__(H3A_THREADS, 2) void gemm_h3a_kernel(H3Args g, Epi epi) {
@@ -198,6 +201,8 @@ __global__ __launch_bounds__(H3A_THREADS, 2) void gemm_h3a_kernel(H3Args g, Epi 
                     }
                 }
                 if constexpr (NEXT) read_b(nsa, tn_c);          // the next tile's fragment of this column tile (raw until take_b)
+                if (H3A_PIN) __builtin_amdgcn_sched_barrier(0);    // keep the reads between the MFMA groups (the scheduler otherwise
+                                                                // issues ~18 MFMAs first and all the reads at the end of the stage)
             };
             group(std::integral_constant<int, 0>{}); group(std::integral_constant<int, 1>{});
             group(std::integral_constant<int, 2>{}); group(std::integral_constant<int, 3>{});

@@ -396,6 +396,12 @@ __device__ __forceinline__ float h3_absmax4(float4 v) { return fmaxf(fmaxf(fabsf
 struct H3PlOut { unsigned char* planes; long pitch; float* scale; float* ss; long seg_stride; };
 template <class E, class = void> struct epi_has_plout { static constexpr bool value = false; };
 template <class E> struct epi_has_plout<E, decltype((void)&E::plout, void())> { static constexpr bool value = true; };
+// optional PLOUT functor member rowout(z, prow, n0) -> float* : the same values ALSO as fp32, written in phase 2 from the staged tile
+// (16 B per lane, full lines) instead of by store instructions inside val().  W2 per launch at config 2: stores inside val() 433 us,
+// rowout 418 us; the residual added in phase 2 from full-line reads instead of aux() 440 us (and a fully unrolled phase 2 made the
+// launch 4x slower: the k loop of one wave and the epilogue of another then evict each other from the instruction cache)
+template <class E, class = void> struct epi_has_rowout { static constexpr bool value = false; };
+template <class E> struct epi_has_rowout<E, decltype((void)&E::rowout, void())> { static constexpr bool value = true; };
 template <class T> __device__ __forceinline__ void h3_assume_row(const T&) {}
 __device__ __forceinline__ void h3_assume_row(long rw) { __builtin_assume(rw >= 0); }
 
@@ -872,7 +878,8 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
             if constexpr (epi_has_aux<Epi>::value) {
                 // 16 half row blocks (tn, tm, half): the aux operands of block i+1 are requested before the stores of block i
                 // (row values and row scales are LDS reads — lgkmcnt, not vmcnt — and are fetched where they are used)
-                decltype(epi.aux(0, 0, 0, RowT{})) ax[2][8];
+                constexpr int AH = H3_AUX_AHEAD;
+                decltype(epi.aux(0, 0, 0, RowT{})) ax[AH + 1][8];
                 auto fetch = [&](int i, int set) {
                     const int tn = i >> 3, tm = (i >> 1) & 3, half = i & 1;
                     int lb = lrow + tm * 32;            // (laundered per block: index arithmetic stays inside its block)
@@ -884,11 +891,12 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
                         ax[set][r8] = epi.aux(z, rowm(lr), min(nn[tn], g.N - 1), row_of(lr));
                     }
                 };
-                fetch(0, 0);
+#pragma unroll
+                for (int i = 0; i < AH; ++i) fetch(i, i % (AH + 1));
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     __builtin_amdgcn_sched_barrier(0);      // (keeps the work of later blocks from being hoisted: registers)
-                    if (i < 15) fetch(i + 1, (i + 1) & 1);
+                    if (i + AH < 16) fetch(i + AH, (i + AH) % (AH + 1));
                     const int tn = i >> 3, tm = (i >> 1) & 3, half = i & 1;
                     RowT rw[8];
                     float sr[8];
@@ -902,7 +910,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
                         sr[r8] = sal[lr];
                     }
 #pragma unroll
-                    for (int r8 = 0; r8 < 8; ++r8) touch(ax[i & 1][r8]);
+                    for (int r8 = 0; r8 < 8; ++r8) touch(ax[i % (AH + 1)][r8]);
                     if (nn[tn] < g.N) {
 #pragma unroll
                         for (int r8 = 0; r8 < 8; ++r8) {
@@ -910,7 +918,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
                             const int lr = lb + (r & 3) + 8 * (r >> 2);
                             if constexpr (!CHECK && epi_has_full<Epi>::value) h3_assume_row(rw[r8]);
                             if (!CHECK || m0 + lr < g.M)
-                                epi.store(z, m0 + lr, nn[tn], acc[tm][tn][r] * (sr[r8] * sc[tn]), rw[r8], cc[tn], ax[i & 1][r8]);
+                                epi.store(z, m0 + lr, nn[tn], acc[tm][tn][r] * (sr[r8] * sc[tn]), rw[r8], cc[tn], ax[i % (AH + 1)][r8]);
                         }
                     }
                 }
@@ -1068,6 +1076,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
                     const float s_ = h3_row_scale(mu, inv);
                     if (pr >= 0) {
                         h3_emit4(pbase + pr * po.pitch, lane, v, s_);
+                        if constexpr (epi_has_rowout<Epi>::value) *reinterpret_cast<f32x4*>(epi.rowout(z, pr, n0) + 4 * lane) = v4;
                         if (lane == 0) {
                             po.scale[(long)bn * po.seg_stride + pr] = inv;
                             if (po.ss) po.ss[(long)bn * po.seg_stride + pr] = q2;
@@ -1078,7 +1087,8 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
             if constexpr (epi_has_aux<Epi>::value) {
                 // 16 half row blocks in the order (half tile hf, tn, tm & 1, half): the aux operands of block i+1 are
                 // requested before the values of block i are formed
-                decltype(epi.aux(0, 0, 0, RowT{})) ax[2][8];
+                constexpr int AH = H3_AUX_AHEAD;
+                decltype(epi.aux(0, 0, 0, RowT{})) ax[AH + 1][8];
                 auto fetch = [&](int i, int set) {
                     const int tn = (i >> 2) & 1, tm = 2 * (i >> 3) + ((i >> 1) & 1), half = i & 1;
                     int lb = lrow + tm * 32;
@@ -1090,12 +1100,13 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
                         ax[set][r8] = epi.aux(z, rowm(lr), nn[tn], row_of(lr));
                     }
                 };
-                fetch(0, 0);
+#pragma unroll
+                for (int i = 0; i < AH; ++i) fetch(i, i % (AH + 1));
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (i == 8) __syncthreads();             // phase 2 of the first half has read the tile
-                    if (i < 15) fetch(i + 1, (i + 1) & 1);
+                    if (i + AH < 16) fetch(i + AH, (i + AH) % (AH + 1));
                     const int tn = (i >> 2) & 1, tmh = (i >> 1) & 1, tm = 2 * (i >> 3) + tmh, half = i & 1;
                     RowT rw[8];
                     float sr[8];
@@ -1109,13 +1120,13 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
                         sr[r8] = sal[lr];
                     }
 #pragma unroll
-                    for (int r8 = 0; r8 < 8; ++r8) touch(ax[i & 1][r8]);
+                    for (int r8 = 0; r8 < 8; ++r8) touch(ax[i % (AH + 1)][r8]);
 #pragma unroll
                     for (int r8 = 0; r8 < 8; ++r8) {
                         const int r = half * 8 + r8;
                         const int lr = lb + (r & 3) + 8 * (r >> 2);
                         float v = 0.f;
-                        if (!CHECK || m0 + lr < g.M) v = epi.val(z, m0 + lr, nn[tn], acc[tm][tn][r] * (sr[r8] * sc[tn]), rw[r8], cc[tn], ax[i & 1][r8]);
+                        if (!CHECK || m0 + lr < g.M) v = epi.val(z, m0 + lr, nn[tn], acc[tm][tn][r] * (sr[r8] * sc[tn]), rw[r8], cc[tn], ax[i % (AH + 1)][r8]);
                         const int rl = lr - wm * 64 - (tm - tmh) * 32;          // (wm*128 + tm*32 + x) -> wm*64 + tmh*32 + x
                         T[rl * 256 + ((tn * 128 + lcol) ^ (((rl >> 2) & 1) << 5))] = v;
                     }

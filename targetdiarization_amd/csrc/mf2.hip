@@ -250,7 +250,9 @@ struct EpiBiasResidualPl {   // the same, and the new x rows also as planes with
     __device__ float col(int, int n) const { return b[n]; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
     __device__ float aux(int, int m, int n, EpiNone) const { return x[(long)m * (int)ld + n]; }
-    __device__ float val(int, int m, int n, float v, EpiNone, float c, float xo) const { const float r = xo + (v + c); x[(long)m * (int)ld + n] = r; return r; }
+    __device__ float val(int, int, int, float v, EpiNone, float c, float xo) const { return xo + (v + c); }
+    __device__ float* rowout(int, long m, int n0) const { return x + m * ld + n0; }          // the fp32 x rows, from phase 2 (full lines)
+    // (the launch moves 1.7 GB and sits at ~82 % of the streaming kernels' HBM rate: see epi_has_rowout in gemm_h3.hpp)
     __device__ tdx::H3PlOut plout(int) const { return tdx::H3PlOut{xp, 2048, xs, xss, M}; }
     __device__ long prow(int, int m) const { return m; } };
 struct EpiPosEnc {   // z = acc + pe[s][n]*scale ; x = z                     mossformer2.py:490-496

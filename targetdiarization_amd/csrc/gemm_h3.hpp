@@ -398,8 +398,9 @@ template <class E, class = void> struct epi_has_plout { static constexpr bool va
 template <class E> struct epi_has_plout<E, decltype((void)&E::plout, void())> { static constexpr bool value = true; };
 // optional PLOUT functor member rowout(z, prow, n0) -> float* : the same values ALSO as fp32, written in phase 2 from the staged tile
 // (16 B per lane, full lines) instead of by store instructions inside val().  W2 per launch at config 2: stores inside val() 433 us,
-// rowout 418 us; the residual added in phase 2 from full-line reads instead of aux() 440 us (and a fully unrolled phase 2 made the
-// launch 4x slower: the k loop of one wave and the epilogue of another then evict each other from the instruction cache)
+// rowout 418 us; the residual added in phase 2 from full-line reads instead of aux() 440 us (and a build of that variant with a fully
+// unrolled phase 2 ran the whole launch 4x slower, k loop included — cause not isolated; the shipped kernels miss the instruction
+// cache on <= 0.03 % of their fetches, profiles/r02_pmc_icache.log)
 template <class E, class = void> struct epi_has_rowout { static constexpr bool value = false; };
 template <class E> struct epi_has_rowout<E, decltype((void)&E::rowout, void())> { static constexpr bool value = true; };
 template <class T> __device__ __forceinline__ void h3_assume_row(const T&) {}

@@ -315,6 +315,7 @@ def pipe_bench(args):
                          "whole_path_tflops_per_gpu": sum(fl.values()) * args.steps / dt / 1e12,
                          "whole_path_frac": sum(fl.values()) * args.steps / dt / 1e12 / PEAK_H3_TFLOPS},
             "stage_ms_per_step_rank0": stage_ms,
+            "peak_device_memory_gib_rank0": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
             "stage_tflops_rank0": {k: (fl[a] / (stage_ms[k] * 1e-3) / 1e12 if stage_ms[k] > 0 else None)
                                    for k, a in (("separation+loudness", "separation"), ("embedding+cosine", "embedding"), ("asr_encoder+decoder", "asr_encoder"))},
             "algorithmic_flops_per_step_rank0": fl,

@@ -608,8 +608,11 @@ int attention_core_h3(const unsigned char* qkP, const float* qks, const unsigned
 #endif
         if (oP) {             // the model: gate operands from the planes, o written as planes with per-segment scales / sums of squares
             if (use_h3a()) {  // half-height tiles, two blocks per CU (gemm_h3a.hpp): one block's epilogue under the other's MFMAs
-                static const bool swap = [] { const char* e = getenv("TDX_H3A_SWAP"); return e ? atoi(e) != 0 : false; }();
-                if (swap) std::swap(g.seg[0], g.seg[1]);      // (experiment: the L2-resident lin_q x Kvu segment first)
+                // the L2-resident lin_q x Kvu segment FIRST: the ring fills from cache hits while the first v|u rows (HBM) are on their way
+                // (ring fill 5.1 -> 4.9 us, k loop 27.1 -> 26.1 us per half tile; config 2: 203.3 vs 205.2 ms).  Only the accumulation
+                // order changes; TDX_H3A_SWAP=0 restores the wide kernel's order (then the results are bit-identical to it)
+                static const bool swap = [] { const char* e = getenv("TDX_H3A_SWAP"); return e ? atoi(e) != 0 : true; }();
+                if (swap) std::swap(g.seg[0], g.seg[1]);
                 if (tdx::launch_gemm_h3a<true>(g, B * G, EpiAttnGatePlOut{vuP, st, oP, os, oss, (long)B * S, G, S, Sp, E}, st_) != hipSuccess)
                     return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
                 return TDX_OK;

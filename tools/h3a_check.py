@@ -1,5 +1,6 @@
 """A/B of the attention launch: TDX_H3A=1 (half-height, two blocks per CU) vs TDX_H3A=0 (wide kernel): run twice, compare the saved outputs bit for bit.
-usage: TDX_H3A=0 python tools/h3a_check.py a && TDX_H3A=1 python tools/h3a_check.py b && python tools/h3a_check.py cmp"""
+usage: TDX_H3A=0 python tools/h3a_check.py a && TDX_H3A=1 TDX_H3A_SWAP=0 python tools/h3a_check.py b && python tools/h3a_check.py cmp
+(TDX_H3A_SWAP=0: the wide kernel's segment order; with the default order the results agree to fp32 rounding, not bit for bit)"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -310,7 +310,7 @@ def pipe_bench(args):
                          "launches_timed": gemm_launches, "ms_per_launch": gemm_ms / max(gemm_launches, 1),
                          "algorithmic_flops_per_launch": 2.0 * full_rows * 512 * 2176,
                          "token_rows_per_full_launch": full_rows,
-                         "mfma_pipe_utilisation_pmc": mfma_util,      # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x busy cycles), profiles/r02_e_pmc_sq.json
+                         "mfma_pipe_utilisation_pmc": mfma_util,      # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x busy cycles), profiles/r02_k_pmc_sq.json
                          "traffic_note": "HBM-side bytes per full launch = (FETCH_SIZE x2 + WRITE_SIZE) per token row from the PMC passes in profiles/traffic.json x rows",
                          "whole_path_tflops_per_gpu": sum(fl.values()) * args.steps / dt / 1e12,
                          "whole_path_frac": sum(fl.values()) * args.steps / dt / 1e12 / PEAK_H3_TFLOPS},

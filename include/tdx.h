@@ -13,8 +13,17 @@
  *  - every function returns 0 on success, non-zero TDX_E_* otherwise; no C++ exception
  *    crosses the boundary; tdx_last_error() returns a thread-local message.
  *  - all launches are asynchronous on the given stream; no hipMalloc/hipFree/sync inside
- *    a forward call (graph-capture safe).  Handles are re-entrant per (handle, workspace,
- *    stream) triple: no global mutable state.
+ *    a forward call (graph-capture safe).
+ *  - threading: a handle is immutable after create (weights + tables); every *_forward /
+ *    predict / decode call may be issued concurrently from several host threads on ONE handle
+ *    provided each concurrent call has its OWN workspace and its OWN stream.  The only
+ *    per-call state the library keeps is tdx_mf2's fork/join context (one side stream + three
+ *    events PER CALLER STREAM, created on the first eager forward on that stream under an
+ *    internal mutex; a forward on a stream that is being captured and has no context yet runs
+ *    unforked: same results).  Two calls that share a workspace or a stream must be ordered
+ *    by the caller (the Python host serialises per model object: _lib.HandleGuard).
+ *    tdx_mf2_profile_* and tdx_mf2_enable_taps are single-caller diagnostics (profile slots
+ *    are claimed under the same mutex; do not toggle them while forwards are in flight).
  */
 #ifndef TDX_H
 #define TDX_H

@@ -138,42 +138,137 @@ def check(status: int):
         raise TdxError(f"libtdx status {status}: {lib().tdx_last_error().decode()}")
 
 
+class HandleGuard:
+    """Serialises the calls on ONE model object (one tdx handle, its grow-only workspace and its graph-replay buffers) — the
+    threading contract of include/tdx.h seen from the host side.  The C handles are re-entrant per (workspace, stream) pair; the
+    Python wrappers share one workspace per object, so they serialise instead:
+      * host side: a re-entrant lock held while a forward is enqueued (two threads on one model: one after the other);
+      * device side: an event chain — every call makes ITS stream wait for the event recorded behind the previous call,
+        whatever stream that one ran on, so the shared workspace / static graph buffers never serve two forwards at a time
+        (the reference serves one shared model from a REST handler and a WebSocket worker thread, main.py:42,366-367).
+    Calls on DIFFERENT model objects (separator || target-clip embedding, embeddings || Paraformer) still overlap.
+    Inside a stream capture nothing is waited for or recorded (an event from outside a capture cannot be waited on there);
+    the capturing caller holds the lock for the whole capture."""
+
+    def __init__(self, device):
+        import threading
+        self.device = device
+        self.lock = threading.RLock()
+        self._event = None
+        self._ws = None
+
+    def call(self):
+        return _GuardedCall(self)
+
+    def workspace(self, nbytes: int):
+        """the grow-only workspace (use inside `with guard.call():`).  Before a smaller buffer is dropped the host waits for its
+        last user: the caching allocator would hand the block back to the stream that allocated it, which has not waited."""
+        import torch
+        nbytes = max(int(nbytes), 16)
+        if self._ws is None or self._ws.numel() < nbytes:
+            if self._ws is not None and self._event is not None:
+                self._event.synchronize()
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+
+class _GuardedCall:
+    def __init__(self, g):
+        self.g = g
+
+    def __enter__(self):
+        import torch
+        g = self.g
+        g.lock.acquire()
+        try:
+            self.stream = torch.cuda.current_stream(g.device)
+            self.capturing = torch.cuda.is_current_stream_capturing()
+            if g._event is not None and not self.capturing:
+                self.stream.wait_event(g._event)
+        except BaseException:
+            g.lock.release()
+            raise
+        return g
+
+    def __exit__(self, *exc):
+        import torch
+        g = self.g
+        try:
+            if not self.capturing:
+                if g._event is None:
+                    g._event = torch.cuda.Event()
+                g._event.record(self.stream)      # (re-recording is safe: a wait binds to the record that preceded it)
+        finally:
+            g.lock.release()
+        return False
+
+
 class GraphRunner:
     """HIP-graph replay of a C-ABI forward for SMALL problems (the reference's own call pattern is one clip per call: a
     forward is then hundreds of 10-100 us kernels and the launch gaps are a sizeable part of the latency).  The forwards
     allocate nothing, never synchronise and issue only kernel launches on the caller's stream (include/tdx.h), so a launch
     sequence is captured once per key (shape) with its own static input / output / workspace and replayed.
-    (A hipMemsetAsync inside a captured sequence broke the node order on ROCm 7.2: the forwards contain none.)"""
+    (A hipMemsetAsync inside a captured sequence broke the node order on ROCm 7.2: the forwards contain none.)
 
-    def __init__(self, device, max_entries: int = 8):
+    A key is captured when it is seen the SECOND time (`capture_after`): a capture costs a warm-up forward + the capture + the
+    first replay, which a shape that never comes back (streaming buffers: a new T on almost every call) would pay for nothing —
+    `__call__` returns None for such a call and the caller runs the plain eager forward.  Entries are evicted least recently
+    used first; before an entry's static buffers are dropped the host waits for its last replay (they were allocated on one
+    stream and replayed on others).  Callers serialise their use of one runner (HandleGuard)."""
+
+    def __init__(self, device, max_entries: int = 8, capture_after: int = 2):
+        from collections import OrderedDict
         self.device = device
         self.max_entries = max_entries
-        self._g = {}
+        self.capture_after = capture_after
+        self._g = OrderedDict()
+        self._seen = OrderedDict()
+        self.captures = 0
+
+    def _evict_one(self):
+        _, (g, si, so, ws, last) = self._g.popitem(last=False)
+        last.synchronize()
 
     def __call__(self, key, x, out_shape, ws_bytes: int, launch):
-        """launch(in_tensor, out_tensor, workspace_tensor, stream_handle) issues the forward; returns a fresh output tensor"""
+        """launch(in_tensor, out_tensor, workspace_tensor, stream_handle) issues the forward.  Returns a fresh output tensor, or
+        None when the key has not been seen `capture_after` times yet (run eager)."""
         import torch
         ent = self._g.get(key)
         if ent is None:
-            if len(self._g) >= self.max_entries:
-                self._g.pop(next(iter(self._g)))
+            n = self._seen.pop(key, 0) + 1
+            if n < self.capture_after:
+                self._seen[key] = n
+                while len(self._seen) > 256:
+                    self._seen.popitem(last=False)
+                return None
+            while len(self._g) >= self.max_entries:
+                self._evict_one()
             si = torch.empty_like(x)
             so = torch.empty(out_shape, dtype=torch.float32, device=self.device)
             ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8, device=self.device)
             si.copy_(x)
+            main = torch.cuda.current_stream(self.device)
+            side = torch.cuda.Stream(self.device)
 
             def run():
                 launch(si, so, ws, torch.cuda.current_stream(self.device).cuda_stream)
-            side = torch.cuda.Stream(self.device)
-            side.wait_stream(torch.cuda.current_stream(self.device))
+            side.wait_stream(main)
             with torch.cuda.stream(side):
-                run()                                  # warm-up outside the capture (function attributes, first-use state)
-            torch.cuda.current_stream(self.device).wait_stream(side)
+                run()                                  # warm-up outside the capture, ON THE CAPTURE STREAM (function attributes, first-use
+                                                       # state, the separator's per-stream fork/join context: csrc/mf2.hip side_for)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: another thread's GPU work (a second session on another model object) must not fail this capture
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                 run()
-            ent = self._g[key] = (g, si, so, ws)
-        g, si, so, ws = ent
+            main.wait_stream(side)
+            ent = self._g[key] = [g, si, so, ws, torch.cuda.Event()]
+            self.captures += 1
+        else:
+            self._g.move_to_end(key)
+        g, si, so, ws, last = ent
         si.copy_(x)
         g.replay()
-        return so.clone()
+        out = so.clone()
+        last.record(torch.cuda.current_stream(self.device))
+        return out

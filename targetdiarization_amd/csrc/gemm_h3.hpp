@@ -1169,12 +1169,10 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
 
 template <bool A_TR, bool B_TR, bool PAIRED, bool TWOSEG, class Epi, int VARIANT = 0, bool A_CONV = false>
 inline hipError_t launch_gemm_h3x(H3Args g, int batches, Epi epi, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_kernel<A_TR, B_TR, PAIRED, TWOSEG, Epi, VARIANT, A_CONV>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    // (function-local static: set once, thread-safe — forwards may be issued from several host threads)
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_kernel<A_TR, B_TR, PAIRED, TWOSEG, Epi, VARIANT, A_CONV>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             H3_LDS + H3_LDS_EXTRA);
-        attr_set = true;
-    }
+    (void)attr_rc;
     g.tiles_m = (g.M + H3_BM - 1) / H3_BM;
     g.tiles_n = PAIRED ? g.N / (H3_BN / 2) : (g.N + H3_BN - 1) / H3_BN;
     g.batches = batches;

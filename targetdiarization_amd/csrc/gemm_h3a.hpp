@@ -374,11 +374,9 @@ inline bool h3a_fits(const H3Args& g, bool gate) {
 template <bool TWOSEG, class Epi>
 inline hipError_t launch_gemm_h3a(H3Args g, int batches, Epi epi, hipStream_t st) {
     constexpr bool GATE = epi_has_plout<Epi>::value;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3a_kernel<TWOSEG, Epi>), hipFuncAttributeMaxDynamicSharedMemorySize, H3A_LDS + H3A_EXTRA);
-        attr_set = true;
-    }
+    // (function-local static: set once, thread-safe — forwards may be issued from several host threads)
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3a_kernel<TWOSEG, Epi>), hipFuncAttributeMaxDynamicSharedMemorySize, H3A_LDS + H3A_EXTRA);
+    (void)attr_rc;
     if (batches < 1 || !h3a_fits<TWOSEG>(g, GATE)) return hipErrorInvalidValue;
     g.tiles_m = g.M / 128;
     g.tiles_n = g.N / (GATE ? 128 : 256);

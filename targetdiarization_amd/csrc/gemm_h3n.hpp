@@ -321,11 +321,9 @@ __global__ __launch_bounds__(H3N_THREADS, 2) void gemm_h3n_kernel(H3Args g, Epi 
 template <bool TWOSEG, class Epi, int MFMA_SHAPE = 0>
 inline hipError_t launch_gemm_h3n(H3Args g, int batches, Epi epi, hipStream_t st) {
     static_assert(!epi_has_aux<Epi>::value && !epi_has_plout<Epi>::value, "narrow x3 kernel: store/ptr functors only");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3n_kernel<TWOSEG, Epi, MFMA_SHAPE>), hipFuncAttributeMaxDynamicSharedMemorySize, H3N_LDS + H3N_EXTRA);
-        attr_set = true;
-    }
+    // (function-local static: set once, thread-safe — forwards may be issued from several host threads)
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3n_kernel<TWOSEG, Epi, MFMA_SHAPE>), hipFuncAttributeMaxDynamicSharedMemorySize, H3N_LDS + H3N_EXTRA);
+    (void)attr_rc;
     g.tiles_m = (g.M + 255) / 256;
     g.tiles_n = (g.N + 127) / 128;
     g.batches = batches;

@@ -288,11 +288,9 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3p_kernel(H3Args g, Epi e
 template <bool TWOSEG, class Epi>
 inline hipError_t launch_gemm_h3p(H3Args g, int batches, Epi epi, hipStream_t st) {
     static_assert(!epi_has_aux<Epi>::value && !epi_has_plout<Epi>::value, "pair-stage x3 kernel: store/ptr functors only");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3p_kernel<TWOSEG, Epi>), hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS + H3_LDS_EXTRA);
-        attr_set = true;
-    }
+    // (function-local static: set once, thread-safe — forwards may be issued from several host threads)
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3p_kernel<TWOSEG, Epi>), hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS + H3_LDS_EXTRA);
+    (void)attr_rc;
     g.tiles_m = (g.M + H3_BM - 1) / H3_BM;
     g.tiles_n = (g.N + H3_BN - 1) / H3_BN;
     g.batches = batches;

@@ -338,12 +338,10 @@ __global__ __launch_bounds__(X6_THREADS, 2) void gemm_x6_kernel(GemmArgs g, Epi 
 // >= N are not stored.  PAIRED: N = number of pair columns, multiple of 128.
 template <bool B_KMAJOR, bool PAIRED, bool SHIFT, class Epi>
 inline hipError_t launch_gemm_x6(GemmArgs g, int batches, Epi epi, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6_kernel<B_KMAJOR, PAIRED, SHIFT, Epi>),
+    // (function-local static: set once, thread-safe — forwards may be issued from several host threads)
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6_kernel<B_KMAJOR, PAIRED, SHIFT, Epi>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS);
-        attr_set = true;
-    }
+    (void)attr_rc;
     g.tiles_m = (g.M + X6_BM - 1) / X6_BM;
     g.tiles_n = PAIRED ? g.N / (X6_BN / 2) : (g.N + X6_BN - 1) / X6_BN;
     g.batches = batches;

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -366,10 +367,39 @@ struct tdx_mf2 {
     // the forward's stream, read back by tdx_mf2_profile_collect after the caller synchronised.
     std::vector<hipEvent_t> ev0, ev1;
     size_t ev_used;
-    // small forwards (one window per call): the q/k-head branch of a FLASH layer (conv17<3> -> similarity GEMM) runs on this side
-    // stream next to the v|u branch (conv17<4> -> lin_k^T[v|u]); fork / join by events, so the pair is capturable in a HIP graph
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_heads = nullptr, ev_sim = nullptr;
+    // The q/k-head branch of a FLASH layer (conv17<3> -> similarity GEMM) runs on a side stream next to the v|u branch
+    // (conv17<4> -> lin_k^T[v|u]); fork / join by events, so the pair is capturable in a HIP graph.  The side stream and its three
+    // events belong to the CALLER'S stream, not to the handle: one context per caller stream (created on first use, kept for the
+    // handle's life), so that forwards issued concurrently on different (workspace, stream) pairs share nothing mutable
+    // (include/tdx.h threading contract).  `mu` guards the map and the profile event vectors.
+    struct SideCtx { hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_heads = nullptr, ev_sim = nullptr; };
+    std::mutex mu;
+    std::map<hipStream_t, SideCtx> side_ctx;
+    static constexpr size_t MAX_SIDE_CTX = 64;    // beyond this many distinct caller streams a forward runs unforked (same results)
+    // returns nullptr when no context can be had (stream under capture without one, creation failure, cap reached): the forward then
+    // issues both branches on the caller's stream — slower at one window per call, never wrong
+    SideCtx* side_for(hipStream_t st) {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = side_ctx.find(st);
+        if (it != side_ctx.end()) return &it->second;
+        if (side_ctx.size() >= MAX_SIDE_CTX) return nullptr;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (cs != hipStreamCaptureStatusNone) return nullptr;      // no stream / event creation inside a capture: capture after one eager call on that stream
+        SideCtx c;
+        if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c.ev_heads, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c.ev_sim, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (c.ev_sim) hipEventDestroy(c.ev_sim);
+            if (c.ev_heads) hipEventDestroy(c.ev_heads);
+            if (c.ev_fork) hipEventDestroy(c.ev_fork);
+            if (c.side) hipStreamDestroy(c.side);
+            return nullptr;
+        }
+        return &(side_ctx[st] = c);      // (std::map: the address stays valid while other streams are added)
+    }
 };
 
 namespace {
@@ -940,13 +970,6 @@ int tdx_mf2_create(const tdx_mf2_config* cfg, const void* blob, size_t blob_byte
         e = hipDeviceSynchronize();
         if (e != hipSuccess) { hipFree(h->dev_planes); hipFree(dev); delete h; return tdx::fail_hip(e, __FILE__, __LINE__); }
     }
-    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_heads, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_sim, hipEventDisableTiming) != hipSuccess) {
-        tdx_mf2_destroy(h);
-        return tdx::fail(TDX_E_HIP, "tdx_mf2_create: side stream / events");
-    }
     *out = h;
     return TDX_OK;
 }
@@ -958,10 +981,10 @@ int tdx_mf2_destroy(tdx_mf2* h) {
     if (h->dev_static) hipFree(h->dev_static);
     for (auto e : h->ev0) hipEventDestroy(e);
     for (auto e : h->ev1) hipEventDestroy(e);
-    if (h->ev_fork) hipEventDestroy(h->ev_fork);
-    if (h->ev_heads) hipEventDestroy(h->ev_heads);
-    if (h->ev_sim) hipEventDestroy(h->ev_sim);
-    if (h->side) hipStreamDestroy(h->side);
+    for (auto& kv : h->side_ctx) {
+        hipEventDestroy(kv.second.ev_fork); hipEventDestroy(kv.second.ev_heads); hipEventDestroy(kv.second.ev_sim);
+        hipStreamDestroy(kv.second.side);
+    }
     delete h;
     return TDX_OK;
 }
@@ -974,6 +997,7 @@ int tdx_mf2_enable_taps(tdx_mf2* h, int on) {
 
 int tdx_mf2_profile_enable(tdx_mf2* h, int max_records) {
     if (!h || max_records < 0) return tdx::fail(TDX_E_INVALID, "tdx_mf2_profile_enable: bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
     for (auto e : h->ev0) hipEventDestroy(e);
     for (auto e : h->ev1) hipEventDestroy(e);
     h->ev0.assign(max_records, nullptr); h->ev1.assign(max_records, nullptr); h->ev_used = 0;
@@ -986,6 +1010,7 @@ int tdx_mf2_profile_enable(tdx_mf2* h, int max_records) {
 
 int tdx_mf2_profile_collect(tdx_mf2* h, double* total_ms, int* launches) {
     if (!h || !total_ms || !launches) return tdx::fail(TDX_E_INVALID, "tdx_mf2_profile_collect: null argument");
+    std::lock_guard<std::mutex> lk(h->mu);
     double tot = 0;
     for (size_t i = 0; i < h->ev_used; ++i) {
         float ms = 0.f;
@@ -1048,6 +1073,10 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
     float* stat2 = stat1 + (size_t)B * 512;
     (void)G;
 
+    // fork / join context of THIS caller stream (nullptr: run unforked)
+    static const long fork_rows = [] { const char* e = getenv("TDX_FORK_ROWS"); return e ? atol(e) : FORK_ROWS; }();
+    tdx_mf2::SideCtx* sc = M <= fork_rows ? h->side_for(st) : nullptr;
+
     hipLaunchKernelGGL(tables_kernel, dim3(S), dim3(256), 0, st, h->inv_freq, h->rot_freqs, pe, rc, rsn, S);
     LAUNCH_CHECK();
     // ---- encoder + GroupNorm + 1x1 conv + positional encoding   (mossformer2.py:573, :487-496)
@@ -1070,8 +1099,14 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
         // (zero row at the first token of a sample), channels 256..511 from the row itself — each with its own row scale;
         // the ScaleNorm factor comes from the halves' sums of squares (no pass over x)
         {
-            const bool prof = h->ev_used < h->ev0.size();
-            if (prof) hipEventRecord(h->ev0[h->ev_used], st);
+            // (live profiling is a single-caller diagnostic: the slot is claimed under the lock, the events are recorded on this stream)
+            hipEvent_t pe0 = nullptr, pe1 = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(h->mu);
+                if (h->ev_used < h->ev0.size()) { pe0 = h->ev0[h->ev_used]; pe1 = h->ev1[h->ev_used]; h->ev_used++; }
+            }
+            const bool prof = pe0 != nullptr;
+            if (prof) hipEventRecord(pe0, st);
             tdx::H3Args g{};
             g.seg[0] = tdx::h3_seg(xp, xs, 4L * C, w.hWhq.p, w.hWhq.s, 4L * C, C / 2);
             g.seg[0].a_shift = -1; g.seg[0].a_period = S; g.seg[0].a_zero = zrow;
@@ -1079,13 +1114,12 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
             g.nseg = 2; g.M = (int)M; g.N = HQ;
             EpiHiddenSN<2, true> e{xss, M, S, 0.044194173824159216f, w.ghq, w.bhq, hid, HQ};       // (SiLU in conv17)
             if (launch_linear_x3<true>(g, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
-            if (prof) { hipEventRecord(h->ev1[h->ev_used], st); h->ev_used++; }
+            if (prof) hipEventRecord(pe1, st);
         }
         // small forwards: the q/k-head branch (conv17<3> -> similarity) on the side stream, next to the v|u branch
-        static const long fork_rows = [] { const char* e = getenv("TDX_FORK_ROWS"); return e ? atol(e) : FORK_ROWS; }();
-        const bool fork = h->side && M <= fork_rows;
-        hipStream_t sq = fork ? h->side : st;
-        if (fork && (hipEventRecord(h->ev_fork, st) != hipSuccess || hipStreamWaitEvent(h->side, h->ev_fork, 0) != hipSuccess))
+        const bool fork = sc != nullptr;
+        hipStream_t sq = fork ? sc->side : st;
+        if (fork && (hipEventRecord(sc->ev_fork, st) != hipSuccess || hipStreamWaitEvent(sc->side, sc->ev_fork, 0) != hipSuccess))
             return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
         {
             Conv17Args a{};
@@ -1097,10 +1131,10 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
             q.rot_cos = rc; q.rot_sin = rsn; q.head_stride = (long)B * Sp * QK;
             q.hp = (unsigned char*)qk4; q.hs = qks; q.sv = w.sv_lk; q.silu_in = 1;
             TRY(launch_conv17<3>(q, B, sq));          // the four heads as planes
-            if (fork && hipEventRecord(h->ev_heads, h->side) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+            if (fork && hipEventRecord(sc->ev_heads, sc->side) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
         }
         TRY(attention_core_h3((const unsigned char*)qk4, qks, vuP, nullptr, w.st, B, S, 1024, P.splits, P.kchunk, Abuf, AbufP, Asc, slab, kvu, KvuP,
-                              kvus, nullptr, nullptr, nullptr, st, oP, os, oss, fork ? h->side : nullptr, h->ev_heads, h->ev_sim));
+                              kvus, nullptr, nullptr, nullptr, st, oP, os, oss, fork ? sc->side : nullptr, fork ? sc->ev_heads : nullptr, fork ? sc->ev_sim : nullptr));
         {   // to_out: A = the planes of o with one row scale per 128-channel segment; ScaleNorm from the segments' sums of squares
             tdx::H3Args g{};
             g.seg[0] = tdx::h3_seg(oP, os, 4L * 1024, w.hWo.p, w.hWo.s, 4L * 1024, 1024);

@@ -30,7 +30,7 @@ class ParaformerEncoder:
         self.device = torch.device("cuda", idx)
         _lib.check(self._l.tdx_pfenc_create(num_blocks, buf, len(blob), idx, C.byref(h)))
         self._h = h
-        self._ws = None
+        self._guard = _lib.HandleGuard(self.device)      # calls on this object are serialised (host lock + device event chain)
         self._graphs = _lib.GraphRunner(self.device)
         self.fbank = Fbank("asr", self.device)
         # am.mvn vectors (funasr WavFrontend.apply_cmvn): (x + shift) * scale; identity if absent
@@ -48,16 +48,18 @@ class ParaformerEncoder:
         feats = feats.to(self.device, torch.float32).contiguous()
         B, T, _ = feats.shape
         nb = int(self._l.tdx_pfenc_workspace_bytes(self._h, B, T))
-        if self.graph_rows and B * T <= self.graph_rows:
-            def launch(si, so, ws, st):
-                _lib.check(self._l.tdx_pfenc_forward(self._h, si.data_ptr(), None, B, T, so.data_ptr(), ws.data_ptr(), ws.numel(), st))
-            return self._graphs((B, T), feats, (B, T, 512), nb, launch)
-        if self._ws is None or self._ws.numel() < nb:
-            self._ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
-        out = torch.empty(B, T, 512, device=self.device)
-        st = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(self._l.tdx_pfenc_forward(self._h, feats.data_ptr(), None, B, T, out.data_ptr(), self._ws.data_ptr(), self._ws.numel(), st))
-        return out
+        with self._guard.call():
+            if self.graph_rows and B * T <= self.graph_rows:
+                def launch(si, so, ws, st):
+                    _lib.check(self._l.tdx_pfenc_forward(self._h, si.data_ptr(), None, B, T, so.data_ptr(), ws.data_ptr(), ws.numel(), st))
+                out = self._graphs((B, T), feats, (B, T, 512), nb, launch)    # None until the shape is seen a second time
+                if out is not None:
+                    return out
+            ws = self._guard.workspace(nb)
+            out = torch.empty(B, T, 512, device=self.device)
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(self._l.tdx_pfenc_forward(self._h, feats.data_ptr(), None, B, T, out.data_ptr(), ws.data_ptr(), ws.numel(), st))
+            return out
 
     def __call__(self, wav: torch.Tensor) -> torch.Tensor:
         return self.encode(self.features(wav))
@@ -97,12 +99,7 @@ class ParaformerDecoder:
         self.device = torch.device("cuda", idx)
         _lib.check(self._l.tdx_pfdec_create(num_blocks, vocab, buf, len(blob), idx, C.byref(h)))
         self._h = h
-        self._ws = None
-
-    def _workspace(self, nb):
-        if self._ws is None or self._ws.numel() < nb:
-            self._ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
-        return self._ws
+        self._guard = _lib.HandleGuard(self.device)      # calls on this object are serialised (host lock + device event chain)
 
     def predict(self, enc: torch.Tensor):
         """enc [B,T,512] -> (alphas [B,T+1], embeds [B,T+1,512], counts int32 [B], peaks int32 [B,T+1]) on the device"""
@@ -113,10 +110,11 @@ class ParaformerDecoder:
         counts = torch.empty(B, dtype=torch.int32, device=self.device)
         peaks = torch.empty(B, T + 1, dtype=torch.int32, device=self.device)
         nb = int(self._l.tdx_pfdec_predict_workspace_bytes(self._h, B, T))
-        ws = self._workspace(nb)
-        st = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(self._l.tdx_pfdec_predict(self._h, enc.data_ptr(), B, T, alphas.data_ptr(), emb.data_ptr(), counts.data_ptr(), peaks.data_ptr(),
-                                             ws.data_ptr(), ws.numel(), st))
+        with self._guard.call():
+            ws = self._guard.workspace(nb)
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(self._l.tdx_pfdec_predict(self._h, enc.data_ptr(), B, T, alphas.data_ptr(), emb.data_ptr(), counts.data_ptr(), peaks.data_ptr(),
+                                                 ws.data_ptr(), ws.numel(), st))
         return alphas, emb, counts, peaks
 
     def decode_embeds(self, emb: torch.Tensor, counts: torch.Tensor, enc: torch.Tensor, L: int):
@@ -127,10 +125,11 @@ class ParaformerDecoder:
         ids = torch.empty(B, L, dtype=torch.int32, device=self.device)
         score = torch.empty(B, L, device=self.device)
         nb = int(self._l.tdx_pfdec_decode_workspace_bytes(self._h, B, L, T))
-        ws = self._workspace(nb)
-        st = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(self._l.tdx_pfdec_decode(self._h, emb.data_ptr(), emb.shape[1], counts.data_ptr(), enc.data_ptr(), B, L, T, ids.data_ptr(),
-                                            score.data_ptr(), ws.data_ptr(), ws.numel(), st))
+        with self._guard.call():
+            ws = self._guard.workspace(nb)
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(self._l.tdx_pfdec_decode(self._h, emb.data_ptr(), emb.shape[1], counts.data_ptr(), enc.data_ptr(), B, L, T, ids.data_ptr(),
+                                                score.data_ptr(), ws.data_ptr(), ws.numel(), st))
         return ids, score
 
     def decode(self, enc: torch.Tensor):

@@ -76,6 +76,16 @@ class HotPath:
         self.windows_per_launch = windows_per_launch
         self.asr_rows_per_launch = asr_rows_per_launch
         self.overlap_seconds = float(os.environ.get("TDX_OVERLAP_SECONDS", "1e9"))     # run(): stage overlap on side streams up to this much audio per call
+        # the two side streams of run() live as long as the HotPath (a fresh stream per call would make every call's buffers belong to
+        # another stream of the allocator's pool); created on first use
+        self._side_target = None
+        self._side_asr = None
+
+    def _side_stream(self, which: str):
+        name = "_side_" + which
+        if getattr(self, name) is None:
+            setattr(self, name, torch.cuda.Stream(self.device))
+        return getattr(self, name)
 
     def _dev(self, a):
         """host array or tensor -> 1-D float32 device tensor (the one H2D of the path)"""
@@ -179,7 +189,7 @@ class HotPath:
         if target_clip is not None and self.spk is not None:
             tclip = self._dev(target_clip)
             if overlap:
-                side0 = torch.cuda.Stream(self.device)
+                side0 = self._side_stream("target")
                 side0.wait_stream(main)
                 with torch.cuda.stream(side0):
                     target_embedding = self.spk.embed_device([tclip])[0]
@@ -219,9 +229,11 @@ class HotPath:
         if self.asr is not None and with_asr:
             # (issued after the embedding launches above: the decoder reads its token counts back, and that host wait then
             # overlaps embeddings already queued on the main stream)
+            # (world > 1: no overlap — the multi-rank path has not run on hardware yet (the 8-GPU node is the driver's), so it keeps
+            # the plainest stream picture: one compute stream next to RCCL's own; the overlap is worth <= 1 % at 200-utterance steps)
             side = None
             if overlap and world == 1:
-                side = torch.cuda.Stream(self.device)
+                side = self._side_stream("asr")
                 side.wait_event(sep_done)
             with torch.cuda.stream(side if side is not None else main):
                 if self.dec is not None:

@@ -35,6 +35,7 @@ class MossFormer2Separator:
         with torch.cuda.device(idx):
             _lib.check(self._l.tdx_mf2_create(C.byref(cfg), buf, len(blob), idx, C.byref(h)))
         self._h = h
+        self._guard = _lib.HandleGuard(self.device)      # calls on this object are serialised (host lock + device event chain)
         self._ws = None
         self._taps = False
         self._profiling = False
@@ -73,7 +74,6 @@ class MossFormer2Separator:
     def enable_taps(self, on=True):
         _lib.check(self._l.tdx_mf2_enable_taps(self._h, 1 if on else 0))
         self._taps = on
-        self._ws = None
 
     def profile_enable(self, max_records: int):
         _lib.check(self._l.tdx_mf2_profile_enable(self._h, max_records))
@@ -91,14 +91,6 @@ class MossFormer2Separator:
     def flops(self, B, T):
         return float(self._l.tdx_mf2_flops(self._h, B, T))
 
-    def _workspace(self, B, T):
-        need = self.workspace_bytes(B, T)
-        if need == 0:
-            raise _lib.TdxError(f"bad shape B={B} T={T}")
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
-
     def __call__(self, wav: torch.Tensor) -> torch.Tensor:
         if wav.ndim == 1:
             wav = wav.unsqueeze(0)
@@ -107,26 +99,30 @@ class MossFormer2Separator:
         wav = wav.to(self.device, torch.float32).contiguous()
         B, T = wav.shape
         S = (T - 16) // 8 + 1
-        if self.graph_rows and T >= 16 and B * S <= self.graph_rows and not self._taps and not self._profiling:
-            return self._forward_graph(wav, B, T)
-        ws = self._workspace(B, T)
-        out = torch.empty(B, 2, T, dtype=torch.float32, device=self.device)
-        st = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(self._l.tdx_mf2_forward(self._h, wav.data_ptr(), B, T, out.data_ptr(), ws.data_ptr(), ws.numel(), st))
-        self._last = (B, T)
-        return out
-
-    def _forward_graph(self, wav, B, T):
-        """small forwards: HIP-graph replay (_lib.GraphRunner)"""
         need = self.workspace_bytes(B, T)
         if need == 0:
             raise _lib.TdxError(f"bad shape B={B} T={T}")
+        with self._guard.call():
+            if self.graph_rows and B * S <= self.graph_rows and not self._taps and not self._profiling:
+                out = self._forward_graph(wav, B, T, need)
+                if out is not None:
+                    return out
+            ws = self._guard.workspace(need)
+            out = torch.empty(B, 2, T, dtype=torch.float32, device=self.device)
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(self._l.tdx_mf2_forward(self._h, wav.data_ptr(), B, T, out.data_ptr(), ws.data_ptr(), ws.numel(), st))
+            self._last = (B, T)
+            self._ws = ws
+            return out
 
+    def _forward_graph(self, wav, B, T, need):
+        """small forwards: HIP-graph replay (_lib.GraphRunner) from the second sighting of a shape on; None = run eager"""
         def launch(si, so, ws, st):
             _lib.check(self._l.tdx_mf2_forward(self._h, si.data_ptr(), B, T, so.data_ptr(), ws.data_ptr(), ws.numel(), st))
         out = self._graphs((B, T), wav, (B, 2, T), need, launch)
-        self._last = (B, T)
-        self._ws = self._graphs._g[(B, T)][3]
+        if out is not None:
+            self._last = (B, T)
+            self._ws = self._graphs._g[(B, T)][3]
         return out
 
     forward = __call__
@@ -137,8 +133,9 @@ class MossFormer2Separator:
         n = (2 if name == "mask" else 1) * B * S * 512
         dst = torch.empty(n, dtype=torch.float32, device=self.device)
         cnt = C.c_size_t()
-        st = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(self._l.tdx_mf2_tap(self._h, name.encode(), B, T, self._ws.data_ptr(), dst.data_ptr(), n, C.byref(cnt), st))
+        with self._guard.call():
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(self._l.tdx_mf2_tap(self._h, name.encode(), B, T, self._ws.data_ptr(), dst.data_ptr(), n, C.byref(cnt), st))
         return dst.view(2, B, S, 512) if name == "mask" else dst.view(B, S, 512)
 
     def __del__(self):

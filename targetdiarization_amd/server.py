@@ -8,6 +8,11 @@ dependency); the streaming endpoint drives `model.infer_stream` (target_diarizat
 VAD-buffer router with plug-in detectors) in a worker thread like main.py:330-400; a model without `infer_stream` gets fixed
 `max_buffer_duration` buffers (default 10 s) through `infer()`.
 
+Concurrency: ONE model serves every request, like main.py:42.  The model objects serialise their GPU calls (`_lib.HandleGuard`)
+and `infer()` / each streamed buffer hold the model's `gpu_lock`; here every blocking model call runs in the thread pool (the
+event loop stays free: /health answers during a long inference) and every WebSocket connection gets its OWN session state
+(`model.session()`), so concurrent clients do not share buffers, clocks or target embeddings.
+
     app = create_app(model)          # model: targetdiarization_amd.target_diarization.TargetDiarization (or None: 500 on infer)
     uvicorn.run(app, host="0.0.0.0", port=8000)
 """
@@ -87,6 +92,7 @@ def build_response_data(target_spk: str, final_result: List[dict], target_audio,
 def create_app(model=None, max_buffer_duration: float = 10.0):
     from fastapi import FastAPI, HTTPException, Request, WebSocket, WebSocketDisconnect
     from fastapi.middleware.cors import CORSMiddleware
+    from starlette.concurrency import run_in_threadpool
 
     app = FastAPI(title="Target Diarization API")
     app.add_middleware(CORSMiddleware, allow_origins=["*"], allow_credentials=True, allow_methods=["*"], allow_headers=["*"])
@@ -118,13 +124,16 @@ def create_app(model=None, max_buffer_duration: float = 10.0):
             if "audio_file" not in form:
                 raise HTTPException(status_code=422, detail="audio_file is required")
             audio, sr = decode_wav(form["audio_file"]["data"])
-            audio = to16k(audio, sr)
-            target = None
+            target, tsr = None, 16000
             if "target_file" in form and form["target_file"]["data"]:
-                t, tsr = decode_wav(form["target_file"]["data"])
-                target = to16k(t, tsr)
-            target_spk, final_result, target_audio = app.state.model.infer(wav_file=audio, target_file=target, sampling_rate=16000,
-                                                                           is_single=is_single, output_target_audio=output_target_audio)
+                target, tsr = decode_wav(form["target_file"]["data"])
+
+            def work():         # (blocking, off the event loop; the model serialises concurrent requests itself)
+                a = to16k(audio, sr)
+                t = to16k(target, tsr) if target is not None else None
+                return app.state.model.infer(wav_file=a, target_file=t, sampling_rate=16000, is_single=is_single,
+                                             output_target_audio=output_target_audio)
+            target_spk, final_result, target_audio = await run_in_threadpool(work)
             return {"success": True, "data": build_response_data(target_spk, final_result, target_audio, output_target_audio), "error": None,
                     "processing_time": round(time.time() - start, 3)}
         except HTTPException:
@@ -152,6 +161,8 @@ def create_app(model=None, max_buffer_duration: float = 10.0):
                 import queue
                 import threading
                 inq, outq, loop = queue.Queue(), asyncio.Queue(), asyncio.get_running_loop()
+                # per-connection session state (buffer, clock, target embedding); a model without `session()` is driven directly
+                sess = app.state.model.session() if hasattr(app.state.model, "session") else app.state.model
 
                 def chunks():
                     while True:
@@ -162,8 +173,8 @@ def create_app(model=None, max_buffer_duration: float = 10.0):
 
                 def worker():
                     try:
-                        for spk, res, _ in app.state.model.infer_stream(chunks(), target_file=target, sampling_rate=16000,
-                                                                        is_single=bool(config.get("is_single", False)), output_target_audio=False):
+                        for spk, res, _ in sess.infer_stream(chunks(), target_file=target, sampling_rate=16000,
+                                                             is_single=bool(config.get("is_single", False)), output_target_audio=False):
                             loop.call_soon_threadsafe(outq.put_nowait, ("seg", spk, res))
                     except Exception as e:
                         loop.call_soon_threadsafe(outq.put_nowait, ("err", str(e), None))
@@ -206,8 +217,8 @@ def create_app(model=None, max_buffer_duration: float = 10.0):
                     return
                 audio = np.concatenate(buf)
                 buf = []
-                spk, res, _ = app.state.model.infer(wav_file=audio, target_file=target, sampling_rate=16000,
-                                                    is_single=bool(config.get("is_single", False)), output_target_audio=False)
+                spk, res, _ = await run_in_threadpool(lambda: app.state.model.infer(
+                    wav_file=audio, target_file=target, sampling_rate=16000, is_single=bool(config.get("is_single", False)), output_target_audio=False))
                 for seg in res:
                     await websocket.send_json({"type": "segment_result", "data": {"target_speaker_id": spk, "segment": {
                         "speaker": seg["speaker"], "speaker_type": format_speaker_info(seg["speaker"], spk),

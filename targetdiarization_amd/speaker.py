@@ -28,7 +28,7 @@ class ERes2NetV2:
         with torch.cuda.device(idx):
             _lib.check(self._l.tdx_eres2net_create(buf, len(blob), idx, C.byref(h)))
         self._h = h
-        self._ws = None
+        self._guard = _lib.HandleGuard(self.device)      # calls on this object are serialised (host lock + device event chain)
         self._graphs = _lib.GraphRunner(self.device)
         self.fbank = Fbank("sv", self.device)
 
@@ -42,18 +42,18 @@ class ERes2NetV2:
         nb = int(self._l.tdx_eres2net_workspace_bytes(self._h, B, F))
         if nb == 0:
             raise _lib.TdxError("ERes2NetV2: need at least 9 fbank frames")
-        if self.graph_frames and B * F <= self.graph_frames:
-            def launch(si, so, ws, st):
-                _lib.check(self._l.tdx_eres2net_forward(self._h, si.data_ptr(), B, F, so.data_ptr(), ws.data_ptr(), ws.numel(), st))
-            with torch.cuda.device(self.device):
-                return self._graphs((B, F), feat, (B, 192), nb, launch)
-        if self._ws is None or self._ws.numel() < nb:
-            self._ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
-        out = torch.empty(B, 192, device=self.device)
-        with torch.cuda.device(self.device):
+        with torch.cuda.device(self.device), self._guard.call():
+            if self.graph_frames and B * F <= self.graph_frames:
+                def launch(si, so, ws, st):
+                    _lib.check(self._l.tdx_eres2net_forward(self._h, si.data_ptr(), B, F, so.data_ptr(), ws.data_ptr(), ws.numel(), st))
+                out = self._graphs((B, F), feat, (B, 192), nb, launch)        # None until the shape is seen a second time
+                if out is not None:
+                    return out
+            ws = self._guard.workspace(nb)
+            out = torch.empty(B, 192, device=self.device)
             st = torch.cuda.current_stream(self.device).cuda_stream
-            _lib.check(self._l.tdx_eres2net_forward(self._h, feat.data_ptr(), B, F, out.data_ptr(), self._ws.data_ptr(), self._ws.numel(), st))
-        return out
+            _lib.check(self._l.tdx_eres2net_forward(self._h, feat.data_ptr(), B, F, out.data_ptr(), ws.data_ptr(), ws.numel(), st))
+            return out
 
     def __call__(self, wav: torch.Tensor) -> torch.Tensor:
         """wav [B,N] in [-1,1] -> [B,192]; all B clips share N (bucket by length)."""

@@ -18,6 +18,7 @@ path: inputs are 16 kHz mono float arrays.
 from __future__ import annotations
 
 import math
+import threading
 from typing import Callable, Optional
 
 import numpy as np
@@ -54,6 +55,11 @@ class TargetDiarization:
         self.token_list = token_list          # funasr's tokens.json (absent here): ids -> text; None -> "<id>" placeholders
         self.hp = HotPath(sep_state_dict, spk_state_dict, asr_state_dict, cuda_device=cuda_device, mdx_model=mdx_model,
                           mdx_weights_file=mdx_weights_file)
+        # One model serves every request of the reference's server (main.py:42): REST handlers and WebSocket worker threads call
+        # into it concurrently.  Each model object of the hot path serialises its own calls (_lib.HandleGuard); this lock keeps a
+        # whole infer() — and, in stream mode, the processing of one released buffer — together, so that concurrent requests
+        # interleave at request / buffer granularity and every result equals the one a lone caller gets.
+        self.gpu_lock = threading.RLock()
 
     # ---- small DSP helpers kept from AudioProcessor ------------------------------------------
     @staticmethod
@@ -312,6 +318,10 @@ class TargetDiarization:
         return (x.reshape(-1, ch) if ch > 1 else x), sr
 
     def infer(self, wav_file, target_file=None, sampling_rate: int = 16000, is_single: bool = False, output_target_audio: bool = True):
+        with self.gpu_lock:
+            return self._infer(wav_file, target_file, sampling_rate, is_single, output_target_audio)
+
+    def _infer(self, wav_file, target_file, sampling_rate, is_single, output_target_audio):
         wav, sr = self.read_audio(wav_file, sampling_rate)
         audio = self.audio_preprocess(wav, sr)
         target_embedding = None

@@ -12,6 +12,7 @@ text, the "1"/"0" speaker labels and the running clock — follows the reference
 accepted and recorded but the NAR decoder has no prompt input."""
 from __future__ import annotations
 
+import copy
 import re
 from typing import Callable, Generator, Optional
 
@@ -30,10 +31,22 @@ class TargetDiarizationStream(TargetDiarization):
                             ("max_buffer_duration", max_buffer_duration), ("vad_min_silence", vad_min_silence),
                             ("loudness_diff_threshold", loudness_diff_threshold), ("stream_vad", stream_vad or _whole_clip_vad)):
             setattr(self, name, value)
-        # session state
+        self._reset_session()
+
+    def _reset_session(self):
+        # session state (the reference keeps it on the model object, TargetDiarizationStream.py:27-34)
         self.vad_buffer, self.current_buffer_duration = [], 0.0
         self.current_time, self.prev_asr_text = 0.0, ""
         self.target_embedding, self.system_loudness_diff = None, 0.0
+
+    def session(self) -> "TargetDiarizationStream":
+        """A per-connection view of this model: shares the hot path, the plug-ins, the configuration and `gpu_lock`, owns its
+        session state (buffer, clock, target embedding, loudness reference).  The reference keeps that state on the one shared
+        model, so two WebSocket clients overwrite each other's buffers; the server here opens one session per connection.
+        `model.infer_stream(...)` itself still works like the reference (state on the object: one stream at a time)."""
+        s = copy.copy(self)
+        s._reset_session()
+        return s
 
     # ---- helpers --------------------------------------------------------------------------------
     def clear_vad_buffer(self):
@@ -73,27 +86,34 @@ class TargetDiarizationStream(TargetDiarization):
                 raise ValueError("infer_stream(): pass the target clip as numpy audio (file decoding is outside the MI355X hot path)")
             target = target_file.copy()
             if target.shape[0] / sampling_rate >= 1.0:
-                self.system_loudness_diff = self.meter_loudness(self.chunk_preprocess(target, sampling_rate)) + 23.0
-                target = self.audio_preprocess(target, sampling_rate, stream_mode=True)
-                v = self.vad(target)
-                if v:
-                    if v[-1][1] - v[0][0] < 4.0:
-                        print("WARNING: The valid speaking duration of target audio is less than 4s. This may cause a bad result.")
-                    target = self.split_audio_by_time(target, v[0][0], v[-1][1])
-                self.target_embedding = self._embedding(target)
+                with self.gpu_lock:
+                    self.system_loudness_diff = self.meter_loudness(self.chunk_preprocess(target, sampling_rate)) + 23.0
+                    target = self.audio_preprocess(target, sampling_rate, stream_mode=True)
+                    v = self.vad(target)
+                    if v:
+                        if v[-1][1] - v[0][0] < 4.0:
+                            print("WARNING: The valid speaking duration of target audio is less than 4s. This may cause a bad result.")
+                        target = self.split_audio_by_time(target, v[0][0], v[-1][1])
+                    self.target_embedding = self._embedding(target)
+        # (the lock is held while ONE chunk / buffer is processed, never while waiting for the next chunk or while the consumer
+        # holds a yielded result)
         try:
             for pcm_chunk in audio_stream_generator:
-                pcm_chunk = self.chunk_preprocess(pcm_chunk, sampling_rate)
-                for result in self.process_vad_chunk(pcm_chunk, is_single):
+                with self.gpu_lock:
+                    pcm_chunk = self.chunk_preprocess(pcm_chunk, sampling_rate)
+                    results = list(self.process_vad_chunk(pcm_chunk, is_single))
+                for result in results:
                     asr_result, target_audio = self.asr_audio_parser([result], "1", output_target_audio)
                     yield "1", asr_result, target_audio
         finally:
             if self.vad_buffer:
                 combined = np.concatenate(self.vad_buffer)
-                for result in self.process_single_chunk(combined, is_single):
+                with self.gpu_lock:
+                    results = list(self.process_single_chunk(combined, is_single))
+                self.clear_vad_buffer()
+                for result in results:
                     asr_result, target_audio = self.asr_audio_parser([result], "1", output_target_audio)
                     yield "1", asr_result, target_audio
-                self.clear_vad_buffer()
 
     # ---- VAD buffer router (:81-110) ------------------------------------------------------------
     def process_vad_chunk(self, pcm_chunk: np.ndarray, is_single: bool):

@@ -121,3 +121,93 @@ def test_websocket_drives_a_streaming_session():
     segs = [m["data"]["segment"] for m in msgs if m["type"] == "segment_result"]
     assert [s_["text"] for s_ in segs] == ["seg0", "seg1", "seg2"] and [s_["speaker_type"] for s_ in segs] == ["target", "other", "target"]
     assert segs[2]["timerange"] == [1.0, 1.5]
+
+
+def test_two_stream_sessions_and_a_post_share_one_model():
+    """ONE model object behind two open WebSocket streams and a REST request (the reference's arrangement, main.py:42,366-367):
+    every connection has its own session state (buffer, clock, target embedding) and every result equals the serial one."""
+    import threading
+    import targetdiarization_amd.target_diarization as td_mod
+    from tests.test_stream_session import SR, FakeHotPath, energy_vad, tone
+
+    class CountingHotPath(FakeHotPath):
+        depth, max_depth, lock = 0, 0, threading.Lock()
+
+        def encode_streams(self, audios):                 # called inside the model's gpu_lock: never by two threads at once
+            cls = CountingHotPath
+            with cls.lock:
+                cls.depth += 1; cls.max_depth = max(cls.max_depth, cls.depth)
+            import time; time.sleep(0.02)
+            with cls.lock:
+                cls.depth -= 1
+            return list(audios)
+
+    saved = td_mod.HotPath
+    td_mod.HotPath = CountingHotPath
+    try:
+        from targetdiarization_amd.target_diarization_stream import TargetDiarizationStream
+
+        def build():
+            return TargetDiarizationStream(vad=energy_vad, stream_vad=energy_vad, od_pipeline=lambda a: [], max_buffer_duration=30.0,
+                                           decoder=lambda enc: ("x" * max(1, int(np.abs(enc).sum() > 0) * (enc.shape[0] // 1600)), []))
+        sil = np.zeros(SR // 2, np.float32)
+        streams = {"a": [np.concatenate([tone(200, 1.0), sil]), np.concatenate([tone(500, 1.0), sil])],      # target = the 200 Hz voice
+                   "b": [np.concatenate([tone(500, 0.8), sil]), np.concatenate([tone(500, 0.6), sil]), np.concatenate([tone(200, 0.7), sil])]}
+
+        def serial(chunks):
+            out = list(build().infer_stream(iter(chunks)))
+            return [(r[1][0]["speaker"], r[1][0]["text"], [round(t, 3) for t in r[1][0]["timerange"]]) for r in out]
+        want = {k: serial(v) for k, v in streams.items()}
+        assert [w[0] for w in want["a"]] == ["1", "0"] and [w[0] for w in want["b"]] == ["1", "1", "0"]
+
+        model = build()
+        model.infer = lambda **kw: ("0", [{"speaker": "0", "timerange": [0.0, 1.0], "text": "rest", "type": "single", "score": 0.5}], None)
+        app = create_app(model)
+        got, errors = {}, []
+
+        def pcm(x):
+            return base64.b64encode((x * 32767).astype(np.int16).tobytes()).decode()
+
+        def client(name):
+            try:
+                c = TestClient(app)
+                with c.websocket_connect("/diarization/stream") as ws:
+                    ws.send_json({"type": "config", "data": {}})
+                    assert ws.receive_json()["type"] == "config_ack"
+                    for ch in streams[name]:
+                        ws.send_json({"type": "audio_chunk", "data": pcm(ch)})
+                    ws.send_json({"type": "end"})
+                    segs = []
+                    while True:
+                        m = ws.receive_json()
+                        if m["type"] == "segment_result":
+                            s_ = m["data"]["segment"]; segs.append((s_["speaker"], s_["text"], s_["timerange"]))
+                        elif m["type"] == "status":
+                            break
+                        else:
+                            raise AssertionError(m)
+                got[name] = segs
+            except Exception as e:                       # noqa: BLE001
+                errors.append((name, repr(e)))
+
+        def rest():
+            try:
+                j = TestClient(app).post("/diarization/infer", files={"audio_file": ("a.wav", wav_bytes(16000), "audio/wav")}).json()
+                got["rest"] = j["success"] and j["data"]["results"][0]["text"]
+            except Exception as e:                       # noqa: BLE001
+                errors.append(("rest", repr(e)))
+        ts = [threading.Thread(target=client, args=("a",)), threading.Thread(target=client, args=("b",)), threading.Thread(target=rest)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(60)
+        assert not errors, errors
+        # int16 round trip of the chunks: same segmentation, text lengths and (to 1 ms) clocks as the serial float run
+        for k in ("a", "b"):
+            assert [(s_[0], len(s_[1])) for s_ in got[k]] == [(w[0], len(w[1])) for w in want[k]], (k, got[k], want[k])
+            assert all(abs(g[2][0] - w[2][0]) < 2e-3 and abs(g[2][1] - w[2][1]) < 2e-3 for g, w in zip(got[k], want[k]))
+        assert got["rest"] == "rest"
+        assert CountingHotPath.max_depth == 1             # buffers of different sessions were processed one at a time
+        assert model.target_embedding is None and not model.vad_buffer      # the shared model object carries no session state
+    finally:
+        td_mod.HotPath = saved

@@ -88,7 +88,9 @@ int tdx_mf2_profile_collect(tdx_mf2* h, double* total_ms, int* launches);
 
 /* test/diagnostic tap: copy a named intermediate of the LAST forward on (h, workspace)
  * into dst_dev (f32).  names: "enc","z","after_flash0","after_fsmn0","after_stack","mask".
- * Layouts are token-major ([B,S,C]; "mask" is [2,B,S,C]).  Returns element count via *n. */
+ * Layouts are token-major ([B,S,C]; "mask" is [2,B,S,C]).  Returns element count via *n.
+ * "headroom": [num_blocks][2] = the largest |f16| written under each layer's static plane scale for (v|u, lin_k) — the scales
+ * are bounds derived from the weights (2^15 after scaling); 2^15 / value is the headroom the bound left (needs taps). */
 int tdx_mf2_tap(tdx_mf2* h, const char* name, int B, int T, void* workspace_dev,
                 float* dst_dev, size_t dst_elems, size_t* n, void* stream);
 

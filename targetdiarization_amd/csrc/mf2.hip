@@ -331,6 +331,20 @@ __global__ void concat_vu_kernel(const float* __restrict__ v, const float* __res
     vu[i] = c < E ? v[m * E + c] : u[m * E + c - E];
 }
 
+// diagnostics (taps): largest |f16| of a planes buffer — how close the values written under a layer's STATIC scale come to the
+// f16 range (2^15 after scaling = the bound derived from the weights).  out holds the bits of a non-negative float (atomicMax on
+// the bit pattern is then the float maximum).
+__global__ void planes_absmax_kernel(const _Float16* __restrict__ p, long n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf((float)p[i]));
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+__global__ void zero_words_kernel(unsigned* __restrict__ p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
 // ------------------------------------------------------------------ model
 struct H3W { const unsigned char* p; const float* s; };
 struct LayerW {
@@ -409,7 +423,7 @@ struct Plan {
     long M;
     // offsets in floats
     size_t fs, xp, xs, xss, os, oss, zrow, E, z, x, rs, hid, vu, qk4, Abuf, slab, kvu, o, t, hraw, h, hp, hs, vuP, AbufP, Asc, qks, KvuP, kvus, uvpre, uv, f, p, c1, c2, pe, rc, rsn, stat,
-        part, tap0, tap1, mask, total;
+        part, tap0, tap1, mask, hdr, total;
 };
 
 inline size_t al(size_t n) { return (n + 63) / 64 * 64; }
@@ -463,8 +477,8 @@ bool make_plan(const tdx_mf2* h, int B, int T, Plan& P) {
     size_t npart_in = (size_t)B * (P.nchunk1 > P.nchunk2 ? P.nchunk1 : P.nchunk2) * 256 * 2;
     if (npart_in > npart) npart = npart_in;
     P.part = take(npart * 2);   // doubles
-    if (h->taps) { P.tap0 = take(M * C); P.tap1 = take(M * C); P.mask = take(2 * M * C); }
-    else { P.tap0 = P.tap1 = P.mask = 0; }
+    if (h->taps) { P.tap0 = take(M * C); P.tap1 = take(M * C); P.mask = take(2 * M * C); P.hdr = take((size_t)h->L * 2 + 64); }
+    else { P.tap0 = P.tap1 = P.mask = P.hdr = 0; }
     P.total = off;
     return true;
 }
@@ -1079,6 +1093,8 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
 
     hipLaunchKernelGGL(tables_kernel, dim3(S), dim3(256), 0, st, h->inv_freq, h->rot_freqs, pe, rc, rsn, S);
     LAUNCH_CHECK();
+    unsigned* hdr = h->taps ? reinterpret_cast<unsigned*>(ws + P.hdr) : nullptr;       // [L][2] largest scaled |f16| of v|u and lin_k (tap "headroom")
+    if (hdr) { hipLaunchKernelGGL(zero_words_kernel, dim3((2 * h->L + 255) / 256), dim3(256), 0, st, hdr, 2 * h->L); LAUNCH_CHECK(); }
     // ---- encoder + GroupNorm + 1x1 conv + positional encoding   (mossformer2.py:573, :487-496)
     hipLaunchKernelGGL(encoder_kernel, dim3(P.nblk_enc, B), dim3(128), 0, st, wav, h->encT, E, part, T, S, P.nblk_enc);
     LAUNCH_CHECK();
@@ -1131,6 +1147,13 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
             q.rot_cos = rc; q.rot_sin = rsn; q.head_stride = (long)B * Sp * QK;
             q.hp = (unsigned char*)qk4; q.hs = qks; q.sv = w.sv_lk; q.silu_in = 1;
             TRY(launch_conv17<3>(q, B, sq));          // the four heads as planes
+            if (hdr) {
+                hipLaunchKernelGGL(planes_absmax_kernel, dim3(1024), dim3(256), 0, st, reinterpret_cast<const _Float16*>(vuP), (long)B * Sp * HID * 2, hdr + 2 * l);
+                LAUNCH_CHECK();
+                hipLaunchKernelGGL(planes_absmax_kernel, dim3(256), dim3(256), 0, sq, reinterpret_cast<const _Float16*>(qk4) + 3L * B * Sp * 256, (long)B * Sp * 256,
+                                   hdr + 2 * l + 1);
+                LAUNCH_CHECK();
+            }
             if (fork && hipEventRecord(sc->ev_heads, sc->side) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
         }
         TRY(attention_core_h3((const unsigned char*)qk4, qks, vuP, nullptr, w.st, B, S, 1024, P.splits, P.kchunk, Abuf, AbufP, Asc, slab, kvu, KvuP,
@@ -1234,6 +1257,7 @@ int tdx_mf2_tap(tdx_mf2* h, const char* name, int B, int T, void* ws_, float* ds
     else if (s == "after_flash0") off = P.tap0;
     else if (s == "after_fsmn0") off = P.tap1;
     else if (s == "mask") { off = P.mask; cnt = 2 * MC; }
+    else if (s == "headroom") { off = P.hdr; cnt = (size_t)h->L * 2; }     // per layer: largest |f16| written under the static scales of v|u, lin_k
     else return tdx::fail(TDX_E_INVALID, "tdx_mf2_tap: unknown tap " + s);
     if (n) *n = cnt;
     if (dst_elems < cnt) return tdx::fail(TDX_E_INVALID, "tdx_mf2_tap: destination too small");

@@ -30,6 +30,15 @@ def shard_indices(n: int, rank: int, world: int):
     return list(range(rank, n, world))
 
 
+def cluster_embeddings(embeddings, min_cluster_size: int = 2):
+    """The consumer of the gathered [n_total*k,192] block (BASELINE config 5: "all-gather of embeddings ... for clustering"): HDBSCAN*
+    (min_cluster_size 2, euclidean — the reference's setting for speaker embeddings, TargetASR.py:238) on the host, labels [n] with -1
+    = noise.  One D2H of n*768 bytes; O(n^2) float64 arithmetic for the few hundred utterances of a step (clustering.py)."""
+    from .clustering import hdbscan_labels
+    e = embeddings.detach().cpu().numpy() if isinstance(embeddings, torch.Tensor) else np.asarray(embeddings)
+    return hdbscan_labels(e, min_cluster_size=min_cluster_size)
+
+
 def gather_embeddings(local: torch.Tensor, n_total: int, rank: int, world: int, streams: int = 2) -> torch.Tensor:
     """local [n_i*streams, D] (utterances rank, rank+P, ... in order) -> [n_total*streams, D] in
     utterance order on every rank.  One all-gather of equal-size (zero-padded) blocks."""
@@ -168,7 +177,7 @@ class HotPath:
 
     # ---- whole path over a shard ------------------------------------------------------------
     def run(self, utts, target_embedding=None, rank: int = 0, world: int = 1, n_total: int | None = None, with_asr: bool = True,
-            to_host: bool = True, embed_segment: int | None = None, target_clip=None):
+            to_host: bool = True, embed_segment: int | None = None, target_clip=None, cluster: bool = False):
         """utts: THIS rank's utterances (utterance i of the job lives on rank i % world), host arrays or
         device tensors.  Returns dict with the separated streams, the all-gathered embeddings [n_total*k,192]
         (utterance order), cosine scores vs `target_embedding`, and encoder outputs of the local streams.
@@ -177,6 +186,8 @@ class HotPath:
         and embeds each piece — the per-window scoring of a long recording (BASELINE configs[2]/[3]); the all-gather
         then needs every utterance to produce the same number of pieces.
         to_host=False leaves every result on the device (the benchmark's resident-in-HBM boundary).
+        cluster=True: HDBSCAN labels of the gathered embeddings (`cluster_embeddings`, host) as out["cluster_labels"] — read back after
+        every launch of the step has been queued, so the host arithmetic runs under the tail of the device work.
         target_clip: the target speaker's sample as a waveform instead of `target_embedding` (TargetDiarization.infer has both clips
         at hand, :98-121): its embedding is computed on a side stream WHILE the mix is separated.
         The independent stages overlap on HIP streams: target embedding || separation, then speaker embeddings || Paraformer
@@ -244,6 +255,8 @@ class HotPath:
                 for t in out["encoder"]:
                     t.record_stream(main)
                 main.wait_stream(side)
+        if cluster and "embeddings" in out:
+            out["cluster_labels"] = cluster_embeddings(out["embeddings"])
         if to_host:                                   # the one D2H of the path
             out["streams"] = [(p[0].cpu().numpy(), p[1].cpu().numpy()) for p in sep]
             for k in ("embeddings", "scores", "target_embedding"):

@@ -130,12 +130,14 @@ class MossFormer2Separator:
     def tap(self, name: str) -> torch.Tensor:
         B, T = self._last
         S = (T - 16) // 8 + 1
-        n = (2 if name == "mask" else 1) * B * S * 512
+        n = 2 * self.num_blocks if name == "headroom" else (2 if name == "mask" else 1) * B * S * 512
         dst = torch.empty(n, dtype=torch.float32, device=self.device)
         cnt = C.c_size_t()
         with self._guard.call():
             st = torch.cuda.current_stream(self.device).cuda_stream
             _lib.check(self._l.tdx_mf2_tap(self._h, name.encode(), B, T, self._ws.data_ptr(), dst.data_ptr(), n, C.byref(cnt), st))
+        if name == "headroom":        # [L][2]: largest |f16| written under the static scales of (v|u, lin_k); the f16 range ends at 65504
+            return dst.view(self.num_blocks, 2)
         return dst.view(2, B, S, 512) if name == "mask" else dst.view(B, S, 512)
 
     def __del__(self):

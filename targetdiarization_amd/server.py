@@ -89,6 +89,76 @@ def build_response_data(target_spk: str, final_result: List[dict], target_audio,
     return data
 
 
+def load_dotenv(path: str = ".env", environ=None) -> bool:
+    """What main.py:105 gets from python-dotenv (absent here), for the reference's `.env` files (.env.example): KEY=VALUE lines,
+    `#` comment lines, optional `export ` prefix and matching quotes; variables already present in the environment win
+    (load_dotenv's default override=False).  Returns False when the file does not exist."""
+    import os
+    environ = os.environ if environ is None else environ
+    if not os.path.isfile(path):
+        return False
+    with open(path, encoding="utf-8") as f:
+        for line in f:
+            line = line.strip()
+            if not line or line.startswith("#") or "=" not in line:
+                continue
+            if line.startswith("export "):
+                line = line[7:].lstrip()
+            key, value = line.split("=", 1)
+            key, value = key.strip(), value.strip()
+            if len(value) >= 2 and value[0] == value[-1] and value[0] in "\"'":
+                value = value[1:-1]
+            elif " #" in value:
+                value = value.split(" #", 1)[0].rstrip()
+            if key and key not in environ:
+                environ[key] = value
+    return True
+
+
+def env_to_kwargs(environ=None) -> Dict[str, Any]:
+    """main.py:106-129 verbatim in meaning: environment names -> TargetDiarizationStream constructor kwargs; unset variables are left to
+    the constructor defaults, EXCEPT the three flags the reference always passes (VERBOSE_LOG == "1"; IS_VAD_BUFFER and
+    USE_ASR_PROMPT true unless "0").  (ASR_ENGINE is in .env.example but main.py does not read it — neither does this.)"""
+    import os
+    env = os.environ if environ is None else environ
+
+    def num(name, cast):
+        return cast(env[name]) if env.get(name) is not None else None
+    args = {
+        "verbose_log": env.get("VERBOSE_LOG") == "1",
+        "cuda_device": num("CUDA_DEVICE", int),
+        "target_similarity_threshold": num("TARGET_SIMILARITY_THRESHOLD", float),
+        "pyannote_clustering_threshold": num("PYANNOTE_CLUSTERING_THRESHOLD", float),
+        "diarization_pipeline_dir": env.get("DIARIZATION_PIPELINE_DIR"),
+        "od_model_dir": env.get("OD_MODEL_DIR"),
+        "mdx_weights_file": env.get("MDX_WEIGHTS_FILE"),
+        "embedding_model_dir": env.get("EMBEDDING_MODEL_DIR"),
+        "asr_model_dir": env.get("ASR_MODEL_DIR"),
+        "vad_model_dir": env.get("VAD_MODEL_DIR"),
+        "separater_weights_folder": env.get("SEPARATER_WEIGHTS_FOLDER"),
+        "restorer_weights_folder": env.get("RESTORER_WEIGHTS_FOLDER"),
+        "is_vad_buffer": env.get("IS_VAD_BUFFER") != "0",
+        "max_buffer_duration": num("MAX_BUFFER_DURATION", float),
+        "vad_min_silence": num("VAD_MIN_SILENCE", float),
+        "use_asr_prompt": env.get("USE_ASR_PROMPT") != "0",
+        "similarity_threshold": num("SIMILARITY_THRESHOLD", float),
+        "loudness_diff_threshold": num("LOUDNESS_DIFF_THRESHOLD", float),
+    }
+    return {k: v for k, v in args.items() if v is not None}
+
+
+def model_from_env(dotenv_path: str = ".env", environ=None, **plugins):
+    """main.py:101-137 (the startup hook): `.env` -> constructor kwargs -> TargetDiarizationStream.  `plugins`: what the environment
+    cannot carry here — the state dicts (no checkpoint ships with the reference) and the third-party detectors
+    (sep_state_dict, spk_state_dict, asr_state_dict, sd_pipeline, od_pipeline, vad, stream_vad, ...)."""
+    from .target_diarization_stream import TargetDiarizationStream
+    load_dotenv(dotenv_path, environ)
+    kwargs = env_to_kwargs(environ)
+    print("Init args:", kwargs)
+    kwargs.update(plugins)
+    return TargetDiarizationStream(**kwargs)
+
+
 def create_app(model=None, max_buffer_duration: float = 10.0):
     from fastapi import FastAPI, HTTPException, Request, WebSocket, WebSocketDisconnect
     from fastapi.middleware.cors import CORSMiddleware

@@ -8,9 +8,83 @@ the reference.  Error convention: never raise out of a wrapper for
 feature — print and degrade."""
 from __future__ import annotations
 
-from typing import Optional, Union
+from typing import Callable, Optional, Union
 
 import numpy as np
+
+
+def _whole_clip(audio: np.ndarray):
+    return [[0.0, round(audio.shape[0] / 16000.0, 3)]] if audio.shape[0] else []
+
+
+def target_embedding_from_audio(target_audio, embed_many: Callable, vad: Callable, loudness_control: Callable, read_audio: Optional[Callable] = None,
+                                is_preprocess: bool = True, is_cluster: bool = True, audio_input_type: str = "separate",
+                                output_embedding_list: bool = True, verbose_log: bool = False):
+    """TargetASR.get_target_embedding (TargetASR.py:166-258), step for step:
+      1. inputs: one array, or a path / list of paths (read through `read_audio(path) -> 16 kHz mono float32`);
+      2. is_preprocess: per input, FSMN-VAD ranges (`vad`) -> the speech pieces re-joined -> loudness control; an input without
+         speech is dropped (printed);
+      3. nothing left -> a 192-dim zero vector;
+      4. audio_input_type: "merge" = all inputs concatenated, "longest" = the longest, "separate" = those >= 0.4 s, "auto" =
+         longest if >= 3 s, else merge if <= 2 usable inputs, else separate; every clip capped at 30 s;
+      5. one embedding per clip of >= 400 samples (`embed_many(list of clips) -> [n,192]`: ONE bucketed launch sequence here,
+         one model call per clip in the reference), NaN embeddings skipped (printed);
+      6. is_cluster and more than two embeddings: HDBSCAN(min_cluster_size=2, euclidean), noise (-1) dropped unless all is noise;
+      7. output_embedding_list: the list; else zero vector / the single embedding / the mean."""
+    from .clustering import hdbscan_labels
+    sr = 16000
+    if isinstance(target_audio, str):
+        target_audio = [target_audio]
+    if isinstance(target_audio, list):
+        if read_audio is None:
+            raise ValueError("get_target_embedding: path inputs need a read_audio(path) plug-in")
+        audios = [np.asarray(read_audio(p), dtype=np.float32) for p in target_audio]
+    else:
+        audios = [np.asarray(target_audio).copy()]
+    if is_preprocess:
+        kept = []
+        for a in audios:
+            ranges = vad(a)
+            if not ranges:
+                print("Failed in func get_target_embedding: No VAD result.")
+                continue
+            pieces = [a[max(0, int(s * sr)):min(int(e * sr), a.shape[0])] for s, e in ranges]
+            a = pieces[0].copy() if len(pieces) == 1 else np.concatenate(pieces)
+            kept.append(loudness_control(a))
+        audios = kept
+    if not audios:
+        print("Length of embedding_list shouldn't be zero. Return a 192-dim full-zero embedding.")
+        return np.zeros([192], dtype=np.float32)
+    longest = max(audios, key=lambda x: x.shape[0])
+    normal = [a for a in audios if a.shape[0] >= int(sr * 0.4)]
+    merged = audios[0] if len(audios) == 1 else np.concatenate(audios)
+    if audio_input_type == "auto":
+        audio_input_type = "longest" if longest.shape[0] >= 3.0 * sr else ("merge" if len(normal) <= 2 else "separate")
+    audios = [merged] if audio_input_type == "merge" else [longest] if audio_input_type == "longest" else normal
+    audios = [a[:30 * sr] for a in audios]
+    clips = [a for a in audios if a.shape[0] >= 400]
+    embs = np.asarray(embed_many(clips), dtype=np.float32).reshape(len(clips), -1) if clips else np.zeros((0, 192), np.float32)
+    embedding_list = []
+    for e in embs:
+        if np.isnan(e).any():
+            print("NaN value in embedding. Skip.")
+            continue
+        embedding_list.append(e)
+    if verbose_log:
+        print(f"Length of embedding_list before clustering: {len(embedding_list)}")
+    if is_cluster and len(embedding_list) > 2:
+        labels = hdbscan_labels(np.stack(embedding_list), min_cluster_size=2)
+        valid = np.where(labels != -1)[0]
+        if len(valid) > 0:
+            embedding_list = [embedding_list[i] for i in valid]
+    if output_embedding_list:
+        return embedding_list
+    if len(embedding_list) == 0:
+        print("Length of embedding_list shouldn't be zero. Return a 192-dim full-zero embedding.")
+        return np.zeros([192], dtype=np.float32)
+    if len(embedding_list) == 1:
+        return embedding_list[0]
+    return np.mean(embedding_list, axis=0)
 
 
 class TargetASR:
@@ -18,9 +92,13 @@ class TargetASR:
                  vad_model_dir: str = "iic/speech_fsmn_vad_zh-cn-16k-common-pytorch", diarization_model_dir: Optional[str] = None,
                  asr_model_dir: Union[str, list, None] = None, mdx_weights_file: Optional[str] = None,
                  separater_weights_folder: Optional[str] = None, restorer_weights_folder: Optional[str] = None, verbose_log: bool = False,
-                 *, spk_state_dict=None):
+                 *, spk_state_dict=None, vad: Optional[Callable] = None, loudness_control: Optional[Callable] = None):
+        """vad(audio) -> [[start_s, end_s], ...]: FunASR FSMN-VAD (`self.asrp.vad_detection`, third-party) as a plug-in, default = whole clip;
+        loudness_control(audio) -> audio: AudioProcessor.audio_loudness_control (:417-429), default = the BS.1770 host meter"""
         self.cuda_device = cuda_device
         self.verbose_log = verbose_log
+        self.vad = vad or _whole_clip
+        self.loudness_control = loudness_control
         self.embedding = {}
         if spk_state_dict is not None:
             try:
@@ -48,6 +126,20 @@ class TargetASR:
         elif isinstance(wav_file, str):
             wav_file = [wav_file]
         return self.embedding[embedding_model].get_speaker_embedding(wav_file)
+
+    # TargetASR.py:166-258
+    def get_target_embedding(self, target_audio, is_preprocess: bool = True, is_cluster: bool = True, embedding_model: str = "eres2netv2_large",
+                             audio_input_type: str = "separate", output_embedding_list: bool = True):
+        if embedding_model not in self.embedding:
+            raise KeyError(f"embedding model {embedding_model!r} is not loaded")
+        emb = self.embedding[embedding_model]
+        lc = self.loudness_control
+        if lc is None:
+            from .target_diarization import TargetDiarization
+            lc = TargetDiarization.audio_loudness_control
+        return target_embedding_from_audio(target_audio, emb.get_speaker_embeddings, self.vad, lc, read_audio=getattr(emb, "_read_wav", None),
+                                           is_preprocess=is_preprocess, is_cluster=is_cluster, audio_input_type=audio_input_type,
+                                           output_embedding_list=output_embedding_list, verbose_log=self.verbose_log)
 
     # TargetASR.py:491-505
     def is_same_person(self, existed_embeddings, target_embedding: np.ndarray, threshold: float = 0.4, verbose_result: bool = False):

@@ -10,8 +10,9 @@ order of its steps, with two differences that are the point of the rewrite:
       sd_pipeline(audio) -> {"text": [[start, end, label], ...]}        (CAM++ modelscope pipeline, :73,:126)
       od_pipeline(audio) -> [(start, end, "SPEAKER_xx"), ...]           (pyannote itertracks, :84,:132)
       vad(audio)         -> [[start, end], ...] in seconds               (FSMN-VAD, ASRProcessor.py:742)
-      decoder(encoder_out[T',512]) -> (text, [(token, [s, e]), ...])     (CIF + NAR decoder)
-    Defaults: one segment per utterance / no overlap detector / whole clip is speech / empty text.
+      decoder(encoder_out[T',512]) -> (text, [(token, [s, e]), ...][, language])   (CIF + NAR decoder)
+      punctuation(text)  -> text                                          (CT-Transformer, ASRProcessor.py:880-897)
+    Defaults: one segment per utterance / no overlap detector / whole clip is speech / the device decoder / text unchanged.
 Denoising (MDX net body), Apollo restoration, resampling and file decoding are outside the
 path: inputs are 16 kHz mono float arrays.
 """
@@ -43,7 +44,8 @@ class TargetDiarization:
                  cuda_device: int = 0, verbose_log: bool = False, *args,
                  sep_state_dict=None, spk_state_dict=None, asr_state_dict=None,
                  sd_pipeline: Optional[Callable] = None, od_pipeline: Optional[Callable] = None,
-                 vad: Optional[Callable] = None, decoder: Optional[Callable] = None, mdx_model: Optional[Callable] = None, token_list=None, **kwargs):
+                 vad: Optional[Callable] = None, decoder: Optional[Callable] = None, mdx_model: Optional[Callable] = None, token_list=None,
+                 punctuation: Optional[Callable] = None, **kwargs):
         self.target_similarity_threshold = target_similarity_threshold
         self.asr_engine = asr_engine
         self.cuda_device = cuda_device
@@ -53,6 +55,7 @@ class TargetDiarization:
         self.vad = vad or _whole_clip_vad
         self.decoder = decoder
         self.token_list = token_list          # funasr's tokens.json (absent here): ids -> text; None -> "<id>" placeholders
+        self.punctuation = punctuation        # CT-Transformer punctuation restorer (ASRProcessor.punctuation_restore :880-897, third-party): text -> text
         self.hp = HotPath(sep_state_dict, spk_state_dict, asr_state_dict, cuda_device=cuda_device, mdx_model=mdx_model,
                           mdx_weights_file=mdx_weights_file)
         # One model serves every request of the reference's server (main.py:42): REST handlers and WebSocket worker threads call
@@ -64,7 +67,8 @@ class TargetDiarization:
     # ---- small DSP helpers kept from AudioProcessor ------------------------------------------
     @staticmethod
     def split_audio_by_time(audio, start_time, end_time, sampling_rate=16000):
-        return audio[int(start_time * sampling_rate):int(end_time * sampling_rate)].copy()
+        """AudioProcessor.split_audio_by_time (:740-747): clamped to the clip"""
+        return audio[max(0, int(start_time * sampling_rate)):min(int(end_time * sampling_rate), audio.shape[0])].copy()
 
     @staticmethod
     def audio_loudness_control(audio, sampling_rate=16000, target_loudness=-23.0):
@@ -139,17 +143,52 @@ class TargetDiarization:
                 best, best_spk = sum(sc) / len(sc), spk
         return best_spk
 
-    def sd_result_to_target_embedding(self, audio, sd_result, overlap_map):
-        """:551-578 with TargetASR.get_target_embedding (VAD split + HDBSCAN, third-party) reduced to
-        the embedding of the longest speaker's concatenated non-overlap audio."""
+    def _read_16k(self, src):
+        """read_audio + mono + float32 + 16 kHz (what get_target_embedding does with a path, TargetASR.py:172-176)"""
+        wav, sr = self.read_audio(src)
+        a = np.asarray(wav)
+        if a.ndim > 1:
+            a = a.mean(axis=-1)
+        a = a.astype(np.float32) / 32768.0 if a.dtype == np.int16 else a.astype(np.float32)
+        if sr != 16000:
+            a, _ = self.hp.ap.audio_resample(a, sr, 16000)
+        return a
+
+    def get_target_embedding(self, target_audio, is_preprocess: bool = True, is_cluster: bool = True, audio_input_type: str = "separate",
+                             output_embedding_list: bool = True):
+        """TargetASR.get_target_embedding (TargetASR.py:166-258) over the device embedder: VAD pieces re-joined, loudness control,
+        the clip selection rule, ONE bucketed embedding launch for all clips, HDBSCAN(min_cluster_size=2) on the host, mean"""
+        from .target_asr import target_embedding_from_audio
+        return target_embedding_from_audio(target_audio, self.hp.spk.get_speaker_embeddings, self.vad, self.audio_loudness_control,
+                                           read_audio=self._read_16k,
+                                           is_preprocess=is_preprocess, is_cluster=is_cluster, audio_input_type=audio_input_type,
+                                           output_embedding_list=output_embedding_list, verbose_log=self.verbose_log)
+
+    def sd_result_to_target_embedding(self, audio, sd_result, overlap_map, target_spk: str = ""):
+        """:551-578: no segmentation -> the clip itself; else the speaker with the longest total duration (first wins a tie) unless
+        `target_spk` names one; its non-overlap ranges of >= 0.4 s concatenated (the whole clip if none) -> get_target_embedding"""
         if not sd_result:
-            return "", self.hp.spk.get_speaker_embedding(audio)
-        dur = {spk: sum(r[1] - r[0] for r in rs) for spk, rs in sd_result.items()}
-        target = max(dur, key=lambda k: (dur[k], -list(dur).index(k)))
-        sd_single = iv.subtract_overlap(sd_result, overlap_map) if overlap_map else sd_result
-        parts = [self.split_audio_by_time(audio, s, e) for (s, e) in sd_single[target] if e - s >= 0.4]
-        src = np.concatenate(parts) if parts else audio
-        return target, self.hp.spk.get_speaker_embedding(src)
+            return "", self.get_target_embedding(audio, output_embedding_list=False)
+        if not target_spk or target_spk not in sd_result:
+            target_spk = list(sd_result)[0]
+            best = sum(r[1] - r[0] for r in sd_result[target_spk])
+            for spk, rs in sd_result.items():
+                d = sum(r[1] - r[0] for r in rs)
+                if d > best:
+                    target_spk, best = spk, d
+        if overlap_map:
+            sd_result = iv.subtract_overlap(sd_result, overlap_map)
+        # Quirk kept (:568-573): the reference assigns every cut back to `audio_data`, so the second and later ranges are cut out of
+        # the PREVIOUS piece, not out of the recording (usually empty: a later range starts past the first piece's end); when no
+        # range qualifies the embedding comes from whatever `audio_data` holds then — the whole recording.
+        parts, cur = [], audio
+        for (s, e) in sd_result[target_spk]:
+            if e - s < 0.4:
+                continue
+            cur = self.split_audio_by_time(cur, s, e)
+            parts.append(cur)
+        src = np.concatenate(parts, axis=0) if parts else audio
+        return target_spk, self.get_target_embedding(src, output_embedding_list=False)
 
     # ---- hot loop B, batched: separate every overlap segment of the target ---------------------
     def _separate_overlaps(self, audio, ranges, target_embedding):
@@ -219,26 +258,39 @@ class TargetDiarization:
                 encs, dres = self.hp.encode_device(lines, decode=True)
             else:
                 encs = self.hp.encode_streams(lines)
+        from .asr_processor import ASRProcessor
+        punc = self.punctuation if self.punctuation is not None else (lambda t: t)
         k = 0
         for spk, tl in zip(spks, timelines):
             if tl is None:
                 continue
-            text, stamps = ("", [])
+            text, stamps, lang = "", [], []
+            recognised = self.hp.asr is not None and (dres is not None or self.decoder is not None)
+            if not recognised:                       # no recogniser loaded (asr_detection prints and returns nothing): the chunks keep empty texts
+                out.extend(it for it in items if it["speaker"] == spk)
+                continue
             if self.hp.asr is not None:
                 enc = encs[k]
                 if dres is not None:
                     tok = lambda i: self.token_list[i] if self.token_list is not None and i < len(self.token_list) else f"<{i}>"
                     stamps = [(tok(i), [round(a / 1000.0, 3), round(b / 1000.0, 3)]) for seg in dres[k] for i, (a, b) in zip(seg["token_ids"], seg["timestamp"])]
-                    text = "".join(t for t, _ in stamps)
+                    text = " ".join(t for t, _ in stamps)                 # (asr_detection's text: space-separated tokens, ASRProcessor.py:427-437)
                 elif self.decoder is not None:
-                    text, stamps = self.decoder(enc)
+                    text, stamps, *lang = self.decoder(enc)             # (an optional third value: the recogniser's language tag)
                 k += 1
+            if not stamps:
+                # :787-797 the recogniser returned no timestamps: ONE item per speaker over the whole span of the items, carrying the
+                # speaker's timeline (the reference computes the punctuated text here and then stores the raw one — kept)
+                out.append({"speaker": spk, "timerange": [items[0]["timerange"][0], items[-1]["timerange"][1]], "text": text, "type": "single",
+                            "audio": tl})
+                continue
+            # :798-818 tokens go to the chunk whose range, widened to 0.1 s, contains their START; CJK languages join without a space
+            joiner = "" if (lang[0] if lang else ASRProcessor.detect_language(text)) in ("zh", "ja", "ko", "yue") else " "
             for it in items:
                 if it["speaker"] != spk:
                     continue
-                if stamps:
-                    lo, hi = math.floor(it["timerange"][0] * 10) / 10, math.ceil(it["timerange"][1] * 10) / 10
-                    it["text"] = "".join(tok for tok, (s, e) in stamps if lo <= s <= hi)
+                lo, hi = math.floor(it["timerange"][0] * 10) / 10, math.ceil(it["timerange"][1] * 10) / 10
+                it["text"] = punc("".join(joiner + tok for tok, (s, e) in stamps if lo <= s <= hi))
                 out.append(it)
         out.sort(key=lambda x: x["timerange"][0])
         return out

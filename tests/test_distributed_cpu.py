@@ -58,3 +58,46 @@ def test_shard_indices_partition():
             flat = sorted(i for p in parts for i in p)
             assert flat == list(range(n))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def _spk_emb(i, stream):
+    """utterance i, stream s -> a noisy copy of one of three "speaker" centroids (what config 5's clustering consumes)"""
+    g = torch.Generator().manual_seed(77 + (2 * i + stream) % 3)
+    c = torch.randn(192, generator=g)
+    g2 = torch.Generator().manual_seed(1000 * i + stream)
+    return c + 0.05 * torch.randn(192, generator=g2)
+
+
+def _cluster_worker(rank, world, port, n_total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from targetdiarization_amd.pipeline import cluster_embeddings, gather_embeddings, shard_indices
+    mine = shard_indices(n_total, rank, world)
+    local = torch.stack([_spk_emb(i, s) for i in mine for s in (0, 1)])
+    labels = cluster_embeddings(gather_embeddings(local, n_total, rank, world))
+    q.put((rank, [int(x) for x in labels]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_clustering_of_the_gathered_embeddings_world2():
+    """the all-gather feeds the clustering (BASELINE config 5): every rank gets the labels a single rank would compute"""
+    from targetdiarization_amd.pipeline import cluster_embeddings
+    world, n_total = 2, 9
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_cluster_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [int(x) for x in cluster_embeddings(torch.stack([_spk_emb(i, s) for i in range(n_total) for s in (0, 1)]))]
+    assert res[0] == want and res[1] == want
+    # three speakers -> three clusters, every embedding with its centroid's group
+    groups = {}
+    for j, lab in enumerate(want):
+        groups.setdefault(j % 3, set()).add(lab)
+    assert all(len(v) == 1 and -1 not in v for v in groups.values()) and len({next(iter(v)) for v in groups.values()}) == 3

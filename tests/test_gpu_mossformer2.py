@@ -178,6 +178,56 @@ def test_signal_statistics_vs_oracle(sd2, dev):
         assert err <= REL_TOL * max(den, 1e-6), (name, err, den)
 
 
+def test_static_scales_under_heavy_tailed_weights(sd2, dev):
+    """The K-major planes of v|u and lin_k use per-layer STATIC scales derived from the weights (a true bound).  Recipe
+    weights leave ~2^7 of headroom; trained checkpoints can have outlier channels that push the bound far above the typical value,
+    where the f16 split keeps fewer than 22 bits.  Weights with heavy tails — outlier rows x100 in to_hidden / to_qk, OffsetScale
+    gamma up to 20, PReLU slopes in [-2, 2], InstanceNorm affine x50, depthwise taps x8 on some channels — through the 2-block
+    model against the fp64 oracle at the north-star tolerance; no inf / NaN; the observed headroom (f16 range / largest scaled
+    value, tap "headroom") is printed per layer and must stay inside the 2^18 window in which the split keeps 22 bits."""
+    from oracle import mossformer2_oracle as orc
+    from targetdiarization_amd.separator import MossFormer2Separator
+    from targetdiarization_amd.weights import recipe_wave
+    g = torch.Generator().manual_seed(11)
+    sd = {k: v.clone() for k, v in sd2.items()}
+    for l in range(2):
+        p = f"mask_net.mdl.intra_mdl.mossformerM.layers.{l}."
+        for name, rows in ((p + "to_hidden.mdl.1.weight", 2048), (p + "to_qk.mdl.1.weight", 128)):
+            idx = torch.randperm(rows, generator=g)[:5]
+            sd[name][idx] *= 100.0
+            sd[name.replace("weight", "bias")][idx] *= 30.0
+        sd[p + "qk_offset_scale.gamma"] = sd[p + "qk_offset_scale.gamma"] * (1.0 + 7.0 * torch.rand(4, 128, generator=g))       # up to ~20
+        for cw in ("to_hidden.mdl.3.sequential.1.conv.weight", "to_qk.mdl.3.sequential.1.conv.weight"):
+            ch = torch.randperm(sd[p + cw].shape[0], generator=g)[:6]
+            sd[p + cw][ch] *= 8.0
+        q = f"mask_net.mdl.intra_mdl.mossformerM.fsmn.{l}."
+        sd[q + "conv1.1.weight"] = torch.tensor([-1.7 if l == 0 else 1.9])
+        for nm in ("prelu1", "prelu2"):
+            sd[q + f"gated_fsmn.fsmn.conv.{nm}.weight"] = torch.rand(256, generator=g) * 4.0 - 2.0
+        for nm in ("norm1", "norm2"):
+            sd[q + f"gated_fsmn.fsmn.conv.{nm}.weight"] = sd[q + f"gated_fsmn.fsmn.conv.{nm}.weight"] * 50.0
+            sd[q + f"gated_fsmn.fsmn.conv.{nm}.bias"] = sd[q + f"gated_fsmn.fsmn.conv.{nm}.bias"] * 50.0
+    sep = MossFormer2Separator(sd, device=dev, graph_rows=0)
+    sep.enable_taps(True)
+    x = torch.from_numpy(recipe_wave("heavy", 2, 4803))
+    out = sep(x.to(dev))
+    assert torch.isfinite(out).all()
+    ref64 = orc.mossformer2_forward(x.double(), orc.cast_state_dict(sd, torch.float64))
+    ref32 = orc.mossformer2_forward(x, sd)
+    err = float((out.double().cpu() - ref64).norm() / ref64.norm())
+    err32 = float((ref32.double() - ref64).norm() / ref64.norm())
+    hd = sep.tap("headroom").cpu().numpy()
+    base = MossFormer2Separator(sd2, device=dev, graph_rows=0); base.enable_taps(True); base(x.to(dev))
+    hd0 = base.tap("headroom").cpu().numpy()
+    for l in range(2):
+        print(f"layer {l}: headroom (f16 range 2^15 / largest scaled value) v|u 2^{np.log2(32768.0 / hd[l, 0]):.1f} lin_k 2^{np.log2(32768.0 / hd[l, 1]):.1f}"
+              f"   (recipe weights: 2^{np.log2(32768.0 / hd0[l, 0]):.1f}, 2^{np.log2(32768.0 / hd0[l, 1]):.1f})")
+    print(f"rel-L2 vs fp64 oracle: device {err:.3e}, torch fp32 restatement {err32:.3e}")
+    assert (hd > 0).all() and (hd < 32768.0).all()                       # a true bound: nothing reached the f16 range
+    assert (32768.0 / hd).max() < 2.0 ** 18                             # and the largest value sits inside the 22-bit window
+    assert err < REL_TOL, (err, err32)
+
+
 def test_batch_independence_and_determinism(sep24, dev):
     """row b of a batch == the same window alone (reference: 1.1e-6); bit-identical reruns."""
     from targetdiarization_amd.weights import recipe_wave

@@ -104,7 +104,8 @@ def test_infer_with_device_decoder_and_denoiser(gold, sd2):
     spk, res, aud = td.infer(mix, tgt)
     assert spk in ("0", "1") and res
     texts = [r["text"] for r in res]
-    assert any(t for t in texts) and all(t == "" or t.startswith("w") for t in texts)      # recipe weights: arbitrary tokens, but tokens
+    # recipe weights: arbitrary tokens, but tokens; Latin-letter tokens are joined with a leading space each, like the reference (:813-814)
+    assert any(t for t in texts) and all(t == "" or t.startswith(" w") for t in texts)
 
 
 def test_serving_shell_over_the_device_model(gold, sd2):
@@ -151,6 +152,34 @@ def test_streaming_session_on_the_device(gold, sd2):
         assert set(r) >= {"speaker", "timerange", "text", "type"} and r["speaker"] in ("0", "1") and r["type"] == "single" and r["text"]
         assert r["timerange"][0] >= t_prev
         t_prev = r["timerange"][0]
+
+
+def test_infer_without_target_clip_uses_get_target_embedding(gold, sd2):
+    """N1: infer(mix, None) -> sd_result_to_target_embedding (:551-578) -> TargetASR.get_target_embedding (VAD pieces re-joined,
+    loudness control, 30 s cap, one embedding) on the device embedder; list inputs go through the batched launch + HDBSCAN + mean"""
+    from targetdiarization_amd.target_diarization import TargetDiarization
+    from targetdiarization_amd.weights import recipe_eres2netv2_state_dict
+    mix = _load(gold, "chat_mix.wav")
+    sd_rows = {"text": [[0.0, 3.0, 0], [2.4, 5.5, 1], [5.5, 8.6, 0]]}
+    vad = lambda a: [[0.1, round(a.shape[0] / 16000.0 - 0.1, 3)]] if a.shape[0] > 6400 else []
+    td = TargetDiarization(cuda_device=0, sep_state_dict=sd2, spk_state_dict=recipe_eres2netv2_state_dict(0), sd_pipeline=lambda a: sd_rows, vad=vad)
+    spk, res, aud = td.infer(mix, None)
+    assert spk == "0" and res and aud is not None            # speaker 0 has the longer total duration
+    # the embedding the orchestrator used = get_target_embedding of speaker 0's first non-overlap piece (the reference's overwrite quirk)
+    piece = td.split_audio_by_time(mix, 0.0, 3.0)
+    want = td.hp.spk.get_speaker_embedding(td.audio_loudness_control(piece[1600:int(2.9 * 16000)]))
+    _, got = td.sd_result_to_target_embedding(mix, {"0": [(0.0, 3.0), (5.5, 8.6)], "1": [(2.4, 5.5)]}, [])
+    assert got.shape == (192,) and np.allclose(got, want, rtol=1e-4, atol=1e-6)
+    # list input: per-clip embeddings in ONE bucketed launch sequence, clustering, mean
+    clips = [mix[i * 16000:(i + 2) * 16000].copy() for i in range(0, 6, 1)]
+    embs = td.hp.spk.get_speaker_embeddings([c for c in clips])
+    from targetdiarization_amd.target_asr import target_embedding_from_audio
+    out = target_embedding_from_audio([f"c{i}" for i in range(len(clips))], td.hp.spk.get_speaker_embeddings, vad, td.audio_loudness_control,
+                                      read_audio=lambda p: clips[int(p[1:])], is_preprocess=False, is_cluster=False, output_embedding_list=True)
+    assert len(out) == len(clips) and np.allclose(np.stack(out), embs, rtol=1e-4, atol=1e-6)
+    mean = target_embedding_from_audio([f"c{i}" for i in range(len(clips))], td.hp.spk.get_speaker_embeddings, vad, td.audio_loudness_control,
+                                       read_audio=lambda p: clips[int(p[1:])], is_preprocess=False, is_cluster=True, output_embedding_list=False)
+    assert mean.shape == (192,) and np.isfinite(mean).all()
 
 
 def test_infer_accepts_wav_paths_and_other_rates(gold, sd2):

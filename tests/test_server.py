@@ -211,3 +211,31 @@ def test_two_stream_sessions_and_a_post_share_one_model():
         assert model.target_embedding is None and not model.vad_buffer      # the shared model object carries no session state
     finally:
         td_mod.HotPath = saved
+
+
+def test_env_configuration_maps_to_constructor_kwargs(tmp_path, monkeypatch):
+    """N4: main.py:105-129 — the reference's .env names -> TargetDiarizationStream kwargs, verbatim"""
+    import targetdiarization_amd.target_diarization as td_mod
+    from targetdiarization_amd.server import env_to_kwargs, load_dotenv, model_from_env
+    from tests.test_stream_session import FakeHotPath
+    envfile = tmp_path / ".env"
+    envfile.write_text("### TargetDiarization ###\nHF_TOKEN=\n# comment\nCUDA_DEVICE=0\nVERBOSE_LOG=1\nPYANNOTE_CLUSTERING_THRESHOLD=0.0\nASR_ENGINE=paraformer\n"
+                       "ASR_MODEL_DIR=iic/asr\nDIARIZATION_PIPELINE_DIR=iic/sd\nOD_MODEL_DIR=pyannote/od\nMDX_WEIGHTS_FILE=\"mdx/w.onnx\"\n"
+                       "EMBEDDING_MODEL_DIR=iic/emb\nVAD_MODEL_DIR=iic/vad\nSEPARATER_WEIGHTS_FOLDER=checkpoints/mf2\nRESTORER_WEIGHTS_FOLDER=\n"
+                       "TARGET_SIMILARITY_THRESHOLD=0.2\nIS_VAD_BUFFER=0\nMAX_BUFFER_DURATION=12.5\nUSE_ASR_PROMPT=0\nSIMILARITY_THRESHOLD=0.4\n"
+                       "LOUDNESS_DIFF_THRESHOLD=12.0\nexport VAD_MIN_SILENCE=0.25\n", encoding="utf-8")
+    env = {"SIMILARITY_THRESHOLD": "0.55"}                       # already set: the file does not override it (load_dotenv default)
+    assert load_dotenv(str(envfile), env) is True and load_dotenv(str(tmp_path / "missing.env"), env) is False
+    kw = env_to_kwargs(env)
+    assert kw == {"verbose_log": True, "cuda_device": 0, "target_similarity_threshold": 0.2, "pyannote_clustering_threshold": 0.0,
+                  "diarization_pipeline_dir": "iic/sd", "od_model_dir": "pyannote/od", "mdx_weights_file": "mdx/w.onnx",
+                  "embedding_model_dir": "iic/emb", "asr_model_dir": "iic/asr", "vad_model_dir": "iic/vad",
+                  "separater_weights_folder": "checkpoints/mf2", "restorer_weights_folder": "", "is_vad_buffer": False,
+                  "max_buffer_duration": 12.5, "vad_min_silence": 0.25, "use_asr_prompt": False, "similarity_threshold": 0.55,
+                  "loudness_diff_threshold": 12.0}
+    # nothing set: only the three flags the reference always passes
+    assert env_to_kwargs({}) == {"verbose_log": False, "is_vad_buffer": True, "use_asr_prompt": True}
+    monkeypatch.setattr(td_mod, "HotPath", FakeHotPath)
+    m = model_from_env(str(envfile), dict(env), od_pipeline=lambda a: [])
+    assert m.max_buffer_duration == 12.5 and m.is_vad_buffer is False and m.similarity_threshold == 0.55 and m.target_similarity_threshold == 0.2
+    assert m.cuda_device == 0 and m.verbose_log is True and m.loudness_diff_threshold == 12.0 and m.vad_min_silence == 0.25

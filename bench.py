@@ -74,6 +74,56 @@ def synth_mixtures(batch: int, n: int, seed: int) -> np.ndarray:
     return np.clip(out, -1.0, 1.0).astype(np.float32)
 
 
+def synth_conversation(total_s: int, seed: int) -> np.ndarray:
+    """ONE recording of two alternating "speakers" with 20 % overlap.  Speaker k = 0.05*N(0,1) shaped by a
+    4 Hz raised-cosine AM envelope with its own random phase; turns of 4-8 s alternate, every turn runs 20 % of its length into the
+    next speaker's turn (5 ms raised-cosine edges); clipped to [-1,1], f32.  Timing-neutral for the kernels (dense arithmetic)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = total_s * 16000
+    t = np.arange(n, dtype=np.float64) / 16000.0
+    out = np.zeros(n, dtype=np.float64)
+    gates = np.zeros((2, n), dtype=np.float32)
+    pos, k = 0.0, 0
+    while pos < total_s:
+        dur = rng.uniform(4.0, 8.0)
+        a, b = int(pos * 16000), min(n, int((pos + 1.2 * dur) * 16000))
+        gates[k, a:b] = 1.0
+        pos += dur
+        k ^= 1
+    edge = 0.5 * (1.0 - np.cos(np.pi * np.arange(80) / 80.0)).astype(np.float32)
+    for k in range(2):
+        g = np.convolve(gates[k], edge / edge.sum(), mode="same")
+        ph = rng.uniform(0, 2 * np.pi)
+        env = 0.5 * (1.0 - np.cos(2 * np.pi * 4.0 * t + ph))
+        out += 0.05 * rng.standard_normal(n) * env * g
+    return np.clip(out, -1.0, 1.0).astype(np.float32)
+
+
+def kernel_source_sha() -> str:
+    """hash of the sources of the dominant kernel (gemm_h3.hpp + the launch site in mf2.hip): profiles/traffic.json records the hash
+    its PMC passes were taken at, and the line only quotes those recorded counters while the hashes agree"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gemm_h3.hpp", "mf2.hip", "tdx_common.hpp"):
+        h.update(open(os.path.join(ROOT, "targetdiarization_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def recorded_pmc(rows: int):
+    """(traffic bytes for `rows` token rows, MFMA pipe utilisation, note) from the RECORDED PMC passes in profiles/traffic.json — not
+    measured by this run; None when the file is absent or was recorded for other kernel sources"""
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tf):
+        return None, None, "no profiles/traffic.json"
+    tj = json.load(open(tf))
+    sha = tj.get("kernel_source_sha")
+    if sha != kernel_source_sha():
+        return None, None, f"profiles/traffic.json was recorded for kernel sources {sha}, the built library is {kernel_source_sha()}: not quoted"
+    bpr = tj.get("gemm_to_hidden_hbm_bytes_per_token_row")
+    return (bpr * rows if bpr else None), tj.get("mfma_pipe_utilisation"), \
+        f"recorded PMC passes ({tj.get('source')}): HBM-side bytes = (FETCH_SIZE x2 + WRITE_SIZE) per token row x rows of this run's full launch"
+
+
 def host_cores() -> int:
     """CPU threads this process may actually use: min(affinity, cgroup quota), capped at 16
     (the GPU box gives a one-GPU job a 16-CPU share of a much larger host)."""
@@ -184,16 +234,16 @@ def pipe_bench(args):
     if wl in ("cfg3", "cfg4"):
         total_s = 600 if wl == "cfg3" else 1800
         nwin = total_s // 10
-        rec_np = synth_mixtures(nwin, WINDOW, seed=3 if wl == "cfg3" else 4).reshape(-1)       # one long recording
+        rec_np = synth_conversation(total_s, seed=3 if wl == "cfg3" else 4)                     # one long recording
         batches = [[torch.from_numpy(rec_np).to(dev)]]
         n_step_total = 1
         audio_s_per_step = float(total_s)
         embed_segment = WINDOW
         windows_local = nwin
-        desc = (f"BASELINE {'configs[2]' if wl == 'cfg3' else 'configs[3]'}: {total_s} s synthetic conversation = {nwin} x 10 s windows: "
+        desc = (f"BASELINE {'configs[2]' if wl == 'cfg3' else 'configs[3]'}: {total_s} s synthetic conversation (two alternating speakers, 20 % overlap) = {nwin} x 10 s windows: "
                 f"MossFormer2 ({args.windows_per_launch} windows per launch) -> loudness swap -> ERes2NetV2 on every 10 s window of both streams "
                 "+ cosine vs a target embedding" + (" -> Paraformer (SANM encoder, CIF predictor, NAR decoder, argmax tokens + timestamps) on 30 s segments of both streams, punctuation pass-through" if with_asr else "")
-                + "; recipe weights, device-resident")
+                + "; recipe weights; input resident in HBM, results (separated streams, embeddings, scores, tokens) copied to the host inside the timed region")
         sample_window = rec_np[:WINDOW]
     else:   # cfg5
         n_job, per_step = args.utterances, args.utterances_per_step
@@ -210,12 +260,15 @@ def pipe_bench(args):
         desc = (f"BASELINE configs[4]: the {n_job} x 30 s utterance job in batches of {per_step} utterances (one step = one batch, "
                 f"utterance i of a batch on rank i % {world}; strong scaling: the batch does not grow with N): MossFormer2 (3 windows per "
                 "utterance) -> loudness swap -> ERes2NetV2 on both streams -> all-gather of the [n_i*2,192] embedding blocks (RCCL) -> cosine "
-                "scores -> Paraformer (SANM encoder, CIF predictor, NAR decoder) on both streams; recipe weights, device-resident")
+                "scores + HDBSCAN clustering of the gathered embeddings on rank 0 -> Paraformer (SANM encoder, CIF predictor, NAR decoder) on both "
+                "streams; recipe weights; inputs resident in HBM, results copied to the host inside the timed region")
         sample_window = None
 
-    def step(k):
-        utts = batches[k % len(batches)]
-        return hp.run(utts, target, rank, world, n_step_total, with_asr=with_asr, to_host=False, embed_segment=embed_segment)
+    def step(k, inputs=None):
+        utts = inputs if inputs is not None else batches[k % len(batches)]
+        # to_host="results": the D2H of the results is INSIDE the timed region ("... to end of D2H")
+        return hp.run(utts, target, rank, world, n_step_total, with_asr=with_asr, to_host="results", embed_segment=embed_segment,
+                      cluster=(wl == "cfg5" and rank == 0))
 
     def barrier():
         if use_dist:
@@ -231,8 +284,11 @@ def pipe_bench(args):
     sep.profile_enable(launches_per_step * args.steps)
     barrier()
     t0 = time.perf_counter()
+    step_s = []
     for k in range(args.steps):
-        out = step(args.warmup + k)
+        t1 = time.perf_counter()
+        out = step(args.warmup + k)                 # (ends with the host's wait for the D2H copies)
+        step_s.append(time.perf_counter() - t1)
     barrier()
     dt = time.perf_counter() - t0
     gemm_ms, gemm_launches = sep.profile_collect()
@@ -240,8 +296,21 @@ def pipe_bench(args):
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    assert torch.isfinite(out["embeddings"]).all() and torch.isfinite(out["scores"]).all()
+    assert np.isfinite(out["embeddings"]).all() and np.isfinite(out["scores"]).all()
     assert out["embeddings"].shape[0] == out["scores"].shape[0]
+    d2h_bytes = out.get("d2h_bytes", 0)
+    # PCIe-inclusive figure (never `value`): the same step with its input coming from page-locked HOST memory (H2D + step + D2H)
+    pcie = None
+    if rank == 0 or use_dist:
+        host_in = [u.cpu().pin_memory() for u in batches[0]]
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            step(0, inputs=[h.to(dev, non_blocking=True) for h in host_in])
+        barrier()
+        pcie_dt = (time.perf_counter() - t1) / 2
+        pcie = {"ms_per_step": pcie_dt * 1e3, "value": audio_s_per_step / pcie_dt, "h2d_bytes_rank0": sum(h.numel() * 4 for h in host_in),
+                "d2h_bytes_rank0": d2h_bytes, "note": "input uploaded from pinned host memory inside the timed step; 2 steps"}
 
     # one extra, untimed, instrumented step: per-stage times (events around the stages) and FLOP accounting
     stage_ms = None
@@ -289,17 +358,17 @@ def pipe_bench(args):
         gemm_flops_total = 2.0 * rows_total * 512 * 2176 * 24
         ach = gemm_flops_total / (gemm_ms * 1e-3) / 1e12 if gemm_launches else None
         full_rows = min(args.windows_per_launch, n_win_rank) * S
-        traffic = None
-        mfma_util = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            tj = json.load(open(tf))
-            bpr = tj.get("gemm_to_hidden_hbm_bytes_per_token_row")
-            traffic = bpr * full_rows if bpr else None
-            mfma_util = tj.get("mfma_pipe_utilisation")
+        traffic, mfma_util, traffic_note = recorded_pmc(full_rows)
+        n1_ref = None
+        if wl == "cfg5" and world > 1:            # the same workload on ONE GPU, measured this round (the N = 1 default line is configs[3])
+            f = os.path.join(ROOT, "profiles", "r03_bench_cfg5_n1.json")
+            if os.path.exists(f):
+                j = json.loads(open(f).read().strip().splitlines()[-1])
+                n1_ref = {"value": j["value"], "ms_per_step": j["ms_per_step"], "source": "profiles/r03_bench_cfg5_n1.json (`bench.py --workload cfg5`, 1 x MI355X, this round)"}
         line = {
             "metric": METRIC, "value": value, "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if wl == "cfg5" else "weak",
+            "ms_per_step": dt / args.steps * 1e3, "ms_per_step_median": float(np.median(step_s)) * 1e3, "higher_is_better": True,
+            "scaling": "strong" if wl == "cfg5" else "weak",
             "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
             "config": {"workload": desc, "audio_seconds_per_step": audio_s_per_step, "windows_per_launch": args.windows_per_launch,
                        "parallelism": f"{world} rank(s), one process per GPU, utterances sharded round-robin, full weight replica per rank"},
@@ -310,10 +379,14 @@ def pipe_bench(args):
                          "launches_timed": gemm_launches, "ms_per_launch": gemm_ms / max(gemm_launches, 1),
                          "algorithmic_flops_per_launch": 2.0 * full_rows * 512 * 2176,
                          "token_rows_per_full_launch": full_rows,
-                         "mfma_pipe_utilisation_pmc": mfma_util,      # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x busy cycles), profiles/r02_k_pmc_sq.json
-                         "traffic_note": "HBM-side bytes per full launch = (FETCH_SIZE x2 + WRITE_SIZE) per token row from the PMC passes in profiles/traffic.json x rows",
+                         "pmc_recorded_mfma_pipe_utilisation": mfma_util,      # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x busy cycles), recorded pass
+                         "traffic_source": "pmc_recorded (not measured by this run)" if traffic is not None else None,
+                         "traffic_note": traffic_note,
                          "whole_path_tflops_per_gpu": sum(fl.values()) * args.steps / dt / 1e12,
                          "whole_path_frac": sum(fl.values()) * args.steps / dt / 1e12 / PEAK_H3_TFLOPS},
+            "timed_region": "inputs resident in HBM -> all launches -> D2H of the results (streams, embeddings, scores, tokens) into pinned host memory",
+            "pcie_inclusive": pcie,
+            "same_workload_n1": n1_ref,
             "stage_ms_per_step_rank0": stage_ms,
             "peak_device_memory_gib_rank0": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
             "stage_tflops_rank0": {k: (fl[a] / (stage_ms[k] * 1e-3) / 1e12 if stage_ms[k] > 0 else None)
@@ -352,7 +425,7 @@ def cfg1_bench(args):
     def step():
         # H2 on the target clip || H1 (one 8.665 s window) -> H2 on both streams + cosine || H3 on both streams
         return hp.run([mix], target_clip=tgt)
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(args.warmup, 3)):              # (graphs are captured at the second sighting of a shape)
         out = step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -424,11 +497,7 @@ def cfg2_bench(args):
         M = B * S
         gemm_flops = 2.0 * M * 512 * 2176
         ach = gemm_flops / (gemm_ms / max(gemm_launches, 1) * 1e-3) / 1e12 if gemm_launches else None
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            bpr = json.load(open(tf)).get("gemm_to_hidden_hbm_bytes_per_token_row")
-            traffic = bpr * M if bpr else None
+        traffic, mfma_util, traffic_note = recorded_pmc(M)
         line = {
             "metric": "real-time factor (audio-sec/wall-sec), MossFormer2 separation only (sub-measurement of the full pipe), 16kHz mono",
             "value": value, "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -444,6 +513,8 @@ def cfg2_bench(args):
                          "mfma_pipe_executed_tflops": (ach * H3_PASSES) if ach else None,
                          "launches_timed": gemm_launches, "ms_per_launch": gemm_ms / max(gemm_launches, 1),
                          "algorithmic_flops_per_launch": gemm_flops,
+                         "pmc_recorded_mfma_pipe_utilisation": mfma_util,
+                         "traffic_source": "pmc_recorded (not measured by this run)" if traffic is not None else None, "traffic_note": traffic_note,
                          "whole_path_tflops_per_gpu": flops_step * args.steps / dt / 1e12,
                          "whole_path_frac": flops_step * args.steps / dt / 1e12 / PEAK_H3_TFLOPS},
             "algorithmic_flops_per_step_per_gpu": flops_step,
@@ -455,6 +526,38 @@ def cfg2_bench(args):
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------
+# hbm: the HBM-bound kernels of the path at fixed shapes, for `rocprofv3 --kernel-trace --stats` (tools/hbm_table.py turns the
+# per-kernel times into GB/s against the 8 TB/s spec: SURVEY §8d asks a1/a2, the encoder/decoder strided convolutions and the norms
+# to be reported against the HBM roof).  Shapes: MossFormer2 at the config-2 size (32 x 4 s), denoise_vocal (identity net body:
+# the MDX network is a third-party plug-in) on 60 s of 44.1 kHz stereo, fbank SV / ASR + LFR/CMVN on 64 x 10 s.
+# ----------------------------------------------------------------------------------------------
+def hbm_workload(args):
+    from targetdiarization_amd.audio_processor import AudioProcessor
+    from targetdiarization_amd.frontend import Fbank, lfr_cmvn
+    from targetdiarization_amd.separator import MossFormer2Separator
+    from targetdiarization_amd.weights import recipe_state_dict
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    sep = MossFormer2Separator(recipe_state_dict(0, 24), device=dev)
+    wav = torch.from_numpy(synth_mixtures(32, 64000, seed=2)).to(dev)
+    ap = AudioProcessor(is_denoise_vocal=True, mdx_weights_file="mdx/weights/UVR-MDX-NET-Inst_HQ_3.onnx", cuda_device=0, quality=3,
+                        verbose_log=False, mdx_model=lambda spec: spec)
+    rng = np.random.default_rng(9)
+    stereo = (0.1 * rng.standard_normal((60 * 44100, 2))).astype(np.float32)
+    fb_sv, fb_asr = Fbank("sv", dev), Fbank("asr", dev)
+    w10 = torch.from_numpy(synth_mixtures(64, WINDOW, seed=7)).to(dev)
+    shift, scale = torch.zeros(560, device=dev), torch.ones(560, device=dev)
+    for it in range(args.warmup + args.steps):
+        sep(wav)
+        ap.denoise_vocal(stereo, 44100)
+        fb_sv(w10)
+        lfr_cmvn(fb_asr(w10), shift, scale)
+        torch.cuda.synchronize()
+    print(json.dumps({"workload": "hbm", "passes": args.warmup + args.steps,
+                      "shapes": {"mossformer2": [32, 64000], "denoise_vocal": [60 * 44100, 2], "fbank": [64, WINDOW]}}), flush=True)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -520,9 +623,9 @@ def spawn_ranks(args) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default=None, choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"],
+    ap.add_argument("--steps", type=int, default=10)       # warm (3 warm-up iterations), >= 10 timed
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=None, choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "hbm"],
                     help="default: cfg4 (BASELINE configs[3], the full pipe on 1800 s) at one GPU, cfg5 (BASELINE configs[4], the "
                          "1000-utterance job, strong scaling) at more; cfg2 = MossFormer2 only; cfg3 = 600 s without the ASR encoder")
     ap.add_argument("--asr-rows-per-launch", type=int, default=65536, help="LFR frames per Paraformer launch sequence")
@@ -550,6 +653,8 @@ def main():
         return cfg1_bench(args)
     if args.workload == "cfg2":
         return cfg2_bench(args)
+    if args.workload == "hbm":
+        return hbm_workload(args)
     return pipe_bench(args)
 
 

@@ -258,10 +258,25 @@ class HotPath:
         if cluster and "embeddings" in out:
             out["cluster_labels"] = cluster_embeddings(out["embeddings"])
         if to_host:                                   # the one D2H of the path
-            out["streams"] = [(p[0].cpu().numpy(), p[1].cpu().numpy()) for p in sep]
-            for k in ("embeddings", "scores", "target_embedding"):
-                if k in out:
-                    out[k] = out[k].cpu().numpy()
-            if "encoder" in out:
-                out["encoder"] = [t.cpu().numpy() for t in out["encoder"]]
+            # every result is copied into page-locked host memory with non-blocking copies on the main stream and the host waits ONCE
+            # (pageable `.cpu()` copies are staged and block per tensor).  to_host="results": what infer() hands to its caller — the
+            # separated streams, embeddings, scores, tokens; the encoder outputs (an intermediate once the device decoder has produced
+            # the tokens) stay on the device.
+            keep = []
+
+            def down(t):
+                h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                h.copy_(t, non_blocking=True)
+                keep.append(h)
+                return h
+            streams_h = [down(p) for p in sep]
+            small = {k: down(out[k]) for k in ("embeddings", "scores", "target_embedding") if k in out and isinstance(out[k], torch.Tensor)}
+            enc_h = [down(t) for t in out["encoder"]] if "encoder" in out and to_host != "results" else None
+            main.synchronize()
+            out["streams"] = [(h[0].numpy(), h[1].numpy()) for h in streams_h]
+            for k, h in small.items():
+                out[k] = h.numpy()
+            if enc_h is not None:
+                out["encoder"] = [h.numpy() for h in enc_h]
+            out["d2h_bytes"] = sum(h.numel() * h.element_size() for h in keep)
         return out

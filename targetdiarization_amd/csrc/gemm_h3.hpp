@@ -403,6 +403,29 @@ template <class E> struct epi_has_plout<E, decltype((void)&E::plout, void())> { 
 // cache on <= 0.03 % of their fetches, profiles/r02_pmc_icache.log)
 template <class E, class = void> struct epi_has_rowout { static constexpr bool value = false; };
 template <class E> struct epi_has_rowout<E, decltype((void)&E::rowout, void())> { static constexpr bool value = true; };
+// FUSED DEPTHWISE CONVOLUTION epilogue ("CONV"): FFConvM = Linear -> SiLU -> y + dwconv17(y) along the tokens
+// (conv_module.py:180-220) without the fp32 round trip of y through HBM.  The M tiles of such a launch OVERLAP: tile bm
+// computes the GEMM rows [240 bm - 8, 240 bm + 248) and owns the 240 output rows in the middle, the 8 rows on either side
+// are the convolution's halo (recomputed: 256 / 240 = +6.7 % MFMA work).  Per 128-column half of the tile:
+//   phase 1  every lane: y = silu(acc * scales + bias) -> staging tile T[256][128] fp32 in the (then idle) ring
+//   phase 2  wave w owns output rows 8 + 30 w .. + 29, lane l the column pair (2l, 2l+1): sliding 17-row window over T
+//            (ds_read_b64, conflict-free), 17 packed FMAs per output row, then the split with the layer's STATIC scale and
+//            stores of the K-major planes ([row][32-column group][hi 64 B | lo 64 B]: 4 B per lane = (c, c+1) of one plane,
+//            64-B runs) and, for the columns >= u0, of the fp32 copy (8 B per lane, 512-B runs).
+// Rows of another sample (the convolution zero-pads at the ends of a sample) and rows outside [0, M) are masked in a slow path
+// that only the tiles containing a sample boundary take (one in S / 240).  Columns >= conv().ncols (to_qk) are written as
+// plain fp32 by the owner rows.  Functor: the members of a ptr()/put_scaled() functor plus conv() -> H3Conv and act(x).
+struct H3Conv {
+    const float* w; int wld;                 // taps, tap-major [17][wld]
+    int ncols;                               // columns [0, ncols) take the convolution (ncols % 256 == 0)
+    unsigned char* planes; long pitch;       // K-major planes: row pitch in bytes (4 * channels); pad rows are the caller's
+    float sv;                                // static scale multiplier (a bound: no row maximum)
+    float* u32; int u0; long ld32;           // fp32 copy of the columns >= u0: u32[row * ld32 + (c - u0)], row = global row m
+    int S, Sp;                               // rows per sample (conv zero padding at its ends); planes rows per sample
+};
+template <class E, class = void> struct epi_has_conv { static constexpr bool value = false; };
+template <class E> struct epi_has_conv<E, decltype((void)&E::conv, void())> { static constexpr bool value = true; };
+constexpr int H3_CONV_STEP = 240, H3_CONV_HALO = 8;
 template <class T> __device__ __forceinline__ void h3_assume_row(const T&) {}
 __device__ __forceinline__ void h3_assume_row(long rw) { __builtin_assume(rw >= 0); }
 
@@ -436,7 +459,9 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
             bm = tt / g.tiles_n; bn = tt - bm * g.tiles_n;
         }
     }
-    const int m0 = bm * H3_BM;
+    constexpr bool CONV = epi_has_conv<Epi>::value;
+    static_assert(!CONV || (!PAIRED && !A_TR && !B_TR && !A_CONV && epi_has_ptr<Epi>::value && epi_has_rowmul<Epi>::value), "CONV: row-major Linear with a put_scaled() functor");
+    const int m0 = CONV ? bm * H3_CONV_STEP - H3_CONV_HALO : bm * H3_BM;      // (CONV: overlapping tiles, m0 = -8 for the first)
     const int n0 = PAIRED ? bn * (H3_BN / 2) : bn * H3_BN;
     H3_STAMP(0); H3_STAMP_HW();
 
@@ -480,7 +505,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int r = (wave & 3) * 64 + (lane >> 2) + 16 * j;
-                    const int mr = min(m0 + r, g.M - 1);
+                    const int mr = min(max(m0 + r, 0), g.M - 1);
                     const unsigned char* rowp = Ag + (long)(mr + sg.a_shift) * sg.lda;
                     if (sg.a_period && (mr % sg.a_period) == 0) rowp = sg.a_zero;
                     gp[j] = rowp + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
@@ -548,8 +573,8 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
     float sa_own = 0.f;
     RowT rw_own{};
     if (tid < 256) {
-        sa_own = (sl.sa + (long)zl1 * sl.strideSA + (long)zl2 * sl.strideSA2 + (sl.segk ? (long)(sl.K / sl.segk - 1) * sl.strideSeg : 0L))[(long)min(m0 + tid, g.M - 1) * sl.sa_mul];
-        if constexpr (HAS_ROW) rw_own = epi.row(z, min(m0 + tid, g.M - 1));
+        sa_own = (sl.sa + (long)zl1 * sl.strideSA + (long)zl2 * sl.strideSA2 + (sl.segk ? (long)(sl.K / sl.segk - 1) * sl.strideSeg : 0L))[(long)min(max(m0 + tid, 0), g.M - 1) * sl.sa_mul];
+        if constexpr (HAS_ROW) rw_own = epi.row(z, min(max(m0 + tid, 0), g.M - 1));
         if constexpr (epi_has_rowmul<Epi>::value) sa_own *= epi.rowmul(rw_own);
     }
 
@@ -569,7 +594,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
             const float* sa0 = sg0.sa + (long)(z / sg0.zdiv) * sg0.strideSA + (long)zz2 * sg0.strideSA2;
             const float* sa1 = s1.sa + (long)(z / s1.zdiv) * s1.strideSA + (long)(z % s1.zdiv) * s1.strideSA2;
             if (tid < 256) {
-                const int m = min(m0 + tid, g.M - 1);
+                const int m = min(max(m0 + tid, 0), g.M - 1);
                 const bool zr = sg0.a_period && (m % sg0.a_period) == 0;        // zero operand row: any finite factor will do
                 const float f0 = zr ? 1.0f : sa0[(long)(m + sg0.a_shift) * sg0.sa_mul];
                 reinterpret_cast<float*>(lds + H3_LDS)[tid] = f0 / sa1[(long)m * s1.sa_mul];
@@ -1160,6 +1185,135 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
         }
         }
     };
+
+    // ---- CONV epilogue (see H3Conv)
+    auto epilogue_conv = [&]() {
+        if constexpr (CONV) {
+        int lrow = lrow0, lcol = lcol0;
+        asm volatile("" : "+v"(lrow), "+v"(lcol));
+        const H3Conv cv = epi.conv();
+        int nn[2];
+        decltype(epi.col(0, 0)) cc[2];
+        float sc[2];
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            nn[tn] = n0 + tn * 128 + lcol;
+            const int nc = min(nn[tn], g.N - 1);
+            cc[tn] = epi.col(z, nc);
+            sc[tn] = sb[(long)nc * sbm] * epi.colmul(cc[tn]);
+        }
+        touch(cc[0]); touch(cc[1]); touch(sc[0]); touch(sc[1]);
+        if (n0 >= cv.ncols) {
+            // plain columns (to_qk: pre-activation for conv17<3>): the owner rows 8 .. 247 of the tile (every row has one owner)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                if (nn[tn] >= g.N) continue;
+                float* const p0 = epi.ptr(z, m0 + lrow, nn[tn]);
+                const long ldm = epi.ldm();
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int k = tm * 32 + (r & 3) + 8 * (r >> 2);
+                        const int lr = lrow + k;
+                        const RowT rw = row_of(lr);
+                        const float sr = sal[lr];
+                        if (lr >= H3_CONV_HALO && lr < H3_CONV_HALO + H3_CONV_STEP && m0 + lr < g.M)
+                            epi.put_scaled(p0 + k * ldm, acc[tm][tn][r] * (sr * sc[tn]), rw, cc[tn]);
+                    }
+                }
+            }
+            return;
+        }
+        float* const T = reinterpret_cast<float*>(lds);
+        int* const sid = reinterpret_cast<int*>(lds + H3_LDS + 4096);         // sample index of tile row r, -1 outside [0, M)
+        // fast tiles: all 256 rows exist and belong to one sample (wave-uniform)
+        const bool fast = m0 >= 0 && m0 + 255 < g.M && (m0 / cv.S) == ((m0 + 255) / cv.S);
+        if (!fast && tid < 256) { const int m = m0 + tid; sid[tid] = (m >= 0 && m < g.M) ? m / cv.S : -1; }
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        constexpr int KT = 17, HALF = 8, RW = 30;
+        const int r_first = H3_CONV_HALO + RW * wave;                      // this wave's output rows r_first .. r_first + 29
+        __syncthreads();                             // every wave has retired its last fragment reads: the ring is free
+        auto half = [&](auto tnc) {
+            constexpr int tn = decltype(tnc)::value;     // (two instances: the first half's accumulators die after its phase 1)
+            // ---- phase 1: y = act(acc * scales + bias) -> T[row][128]
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int lr = lrow + tm * 32 + 8 * j;                 // rows lr .. lr + 3: one 16-B read of their scales
+                    const f32x4 sr4 = *reinterpret_cast<const f32x4*>(sal + lr);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) T[(lr + i) * 128 + lcol] = (g.dbg & 16) ? acc[tm][tn][4 * j + i] : epi.act(acc[tm][tn][4 * j + i] * (sr4[i] * sc[tn]), cc[tn]);
+                }
+            }
+            // taps of this lane's column pair (issued before the barrier: their latency hides under it)
+            const int colp = n0 + tn * 128 + 2 * lane;
+            v2f w[KT];
+#pragma unroll
+            for (int t = 0; t < KT; ++t) w[t] = *reinterpret_cast<const v2f*>(cv.w + (long)t * cv.wld + colp);
+            __syncthreads();
+            const float* const Tc = T + 2 * lane;
+            // per-lane byte offsets inside a planes row / an fp32 row; the row bases are wave-uniform (scalar + 32-bit offset stores)
+            const unsigned poff = (unsigned)((colp >> 5) * 128 + (colp & 31) * 2);
+            const bool has32 = cv.u32 && colp >= cv.u0;
+            const unsigned uoff = (unsigned)(colp - cv.u0) * 4u;
+            auto emit = [&](v2f o, long prow, long m) {
+                // split with the static scale: (c, c+1) of the hi plane = one dword, of the lo plane another
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const v2f xs = o * v2f{cv.sv, cv.sv};
+                const h2 hi = h2{(_Float16)xs[0], (_Float16)xs[1]};
+                const h2 lo = h2{(_Float16)(xs[0] - (float)hi[0]), (_Float16)(xs[1] - (float)hi[1])};
+                unsigned char* const rowp = cv.planes + prow * cv.pitch;           // uniform
+                if (g.dbg & 4) { if (xs[0] == 123.456f) *reinterpret_cast<h2*>(rowp + poff) = lo; return; }      // (timing: no stores)
+                *reinterpret_cast<h2*>(rowp + poff) = hi;
+                *reinterpret_cast<h2*>(rowp + 64 + poff) = lo;
+                if (has32) *reinterpret_cast<v2f*>(reinterpret_cast<unsigned char*>(cv.u32 + m * cv.ld32) + uoff) = o;
+            };
+            if (fast) {
+                const int b0 = m0 / cv.S;
+                const long prow0 = (long)b0 * cv.Sp + (m0 - b0 * cv.S);     // planes row of tile row 0
+                // the wave's 30 output rows in three runs of 10: a 26-row window in registers, static indices, no shifting
+                constexpr int RUN = 10;
+#pragma unroll 1
+                for (int r0 = r_first; r0 < r_first + RW; r0 += RUN) {
+                    v2f win[RUN + KT - 1];
+#pragma unroll
+                    for (int i = 0; i < RUN + KT - 1; ++i) win[i] = *reinterpret_cast<const v2f*>(Tc + (r0 - HALF + i) * 128);
+#pragma unroll
+                    for (int i = 0; i < RUN; ++i) {
+                        v2f o = win[HALF + i];
+                        if (!(g.dbg & 8)) {                                   // (timing: no taps)
+#pragma unroll
+                            for (int t = 0; t < KT; ++t) o = __builtin_elementwise_fma(w[t], win[i + t], o);
+                        }
+                        emit(o, prow0 + r0 + i, (long)m0 + r0 + i);
+                    }
+                }
+            } else {
+                // slow tiles (a sample boundary or an end of the row range inside the tile): taps of another sample count as zero
+#pragma unroll 1
+                for (int lr = r_first; lr < r_first + RW; ++lr) {
+                    const int so = sid[lr];
+                    if (so < 0) continue;                   // (wave-uniform)
+                    v2f o = *reinterpret_cast<const v2f*>(Tc + lr * 128);
+#pragma unroll
+                    for (int t = 0; t < KT; ++t) {          // (unrolled: w[] must stay in registers)
+                        const int rt = lr + t - HALF;       // 0 .. 255 by construction
+                        if (sid[rt] == so) o = __builtin_elementwise_fma(w[t], *reinterpret_cast<const v2f*>(Tc + rt * 128), o);
+                    }
+                    const long m = (long)m0 + lr;
+                    emit(o, (long)so * cv.Sp + (m - (long)so * cv.S), m);
+                }
+            }
+        };
+        if (g.dbg & 32) return;                      // (timing: no conv epilogue at all)
+        half(std::integral_constant<int, 0>{});
+        __syncthreads();                             // the convolution of the first half has read T
+        half(std::integral_constant<int, 1>{});
+        }
+    };
+    if constexpr (CONV) { epilogue_conv(); H3_STAMP(4); return; }
     bool whole = m0 + 256 <= g.M;
     if constexpr (epi_has_full<Epi>::value) whole = whole && epi.full(z, m0);
     if constexpr (epi_has_plout<Epi>::value) { if (whole) epilogue_pl(std::false_type{}); else epilogue_pl(std::true_type{}); }
@@ -1174,6 +1328,10 @@ inline hipError_t launch_gemm_h3x(H3Args g, int batches, Epi epi, hipStream_t st
                             H3_LDS + H3_LDS_EXTRA);
     (void)attr_rc;
     g.tiles_m = (g.M + H3_BM - 1) / H3_BM;
+    if constexpr (epi_has_conv<Epi>::value) {        // overlapping M tiles: 240 output rows each (see H3Conv)
+        g.tiles_m = (g.M + H3_CONV_STEP - 1) / H3_CONV_STEP;
+        if (batches != 1 || g.seg[0].segk || g.seg[0].kchunk) return hipErrorInvalidValue;
+    }
     g.tiles_n = PAIRED ? g.N / (H3_BN / 2) : (g.N + H3_BN - 1) / H3_BN;
     g.batches = batches;
     dim3 grid;

@@ -75,6 +75,34 @@ struct EpiHiddenSN {
     __device__ void put_scaled(float* p, float v, float, Col2 c) const { *p = v + c.b; }
     __device__ void store(int, int m, int n, float v, float r, Col2 c) const { out[(long)m * (int)ld + n] = v * r * c.a + c.b; }
 };
+// to_hidden + to_qk with the depthwise convolution of v|u FUSED into the epilogue (gemm_h3.hpp H3Conv): the v|u columns leave the
+// launch as K-major planes (+ u in fp32) — y = silu(.) never goes through HBM and conv17<4> is gone; the to_qk columns leave as
+// fp32 pre-activations for conv17<3>, like EpiHiddenSN<2, true>.                   mossformer_block.py:89-102, conv_module.py:180-220
+struct EpiHiddenConv {
+    const float* ss; long M; int S; float cinv; const float* g; const float* b; float* out; long ld;
+    const float* cw; unsigned char* vuP; float sv; float* u32; int Sp;
+    __device__ Col2 col(int, int n) const { return Col2{g[n], b[n]}; }
+    __device__ float row(int, int m) const {
+        float s = ss[M + m]; if (m % S) s += ss[m - 1];
+        return 1.0f / fmaxf(sqrtf(s) * cinv, 1e-5f);
+    }
+    __device__ float* ptr(int, int m, int n) const { return out + (long)m * (int)ld + n; }
+    __device__ long ldm() const { return ld; }
+    __device__ float rowmul(float r) const { return r; }
+    __device__ float colmul(Col2 c) const { return c.a; }
+    __device__ void put_scaled(float* p, float v, float, Col2 c) const { *p = v + c.b; }
+    __device__ void put(float* p, float v, float r, Col2 c) const { *p = v * r * c.a + c.b; }
+    __device__ void store(int, int m, int n, float v, float r, Col2 c) const { out[(long)m * (int)ld + n] = v * r * c.a + c.b; }
+    __device__ float act(float v, Col2 c) const { return siluf_acc(v + c.b); }
+    __device__ tdx::H3Conv conv() const { return tdx::H3Conv{cw, HID, HID, vuP, 4L * HID, sv, u32, HID / 2, (long)(HID / 2), S, Sp}; }
+};
+// pad rows S .. Sp-1 of every sample of the K-major v|u planes = 0 (the split-K lin_k^T [v|u] launch and the attention launch read
+// whole 256-token groups); once per forward when the planes come from the fused epilogue, which only writes the S real rows
+__global__ void zero_pad_rows_kernel(unsigned char* __restrict__ planes, int S, int Sp, long pitch) {
+    const int b = blockIdx.y, r = S + blockIdx.x;
+    uint4* p = reinterpret_cast<uint4*>(planes + ((long)b * Sp + r) * pitch);
+    for (int i = threadIdx.x; i < pitch / 16; i += blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
 struct EpiQuadSim {  // relu(acc/256)^2 with key mask                       mossformer_block.py:256-262
     float* A; int G; int S; float inv_g;
     __device__ bool col(int z, int n) const { return (z % G) * 256 + n < S; }
@@ -693,6 +721,12 @@ inline bool use_h3p() {
     static const bool on = [] { const char* e = getenv("TDX_H3P"); return e ? atoi(e) != 0 : false; }();
     return on;
 }
+// A/B switch: the depthwise convolution of v|u fused into the to_hidden epilogue (gemm_h3.hpp H3Conv).  TDX_FUSE_CONV=0 restores the
+// separate conv17<4> pass (same arithmetic in the same order: bit-identical results).
+inline bool fuse_conv() {
+    static const bool on = [] { const char* e = getenv("TDX_FUSE_CONV"); return e ? atoi(e) != 0 : true; }();
+    return on;
+}
 template <bool TWOSEG, class Epi>
 hipError_t launch_linear_x3(tdx::H3Args g, Epi e, hipStream_t st) {
     if (use_h3p()) return tdx::launch_gemm_h3p<TWOSEG, Epi>(g, 1, e, st);
@@ -1055,6 +1089,10 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
 
     hipLaunchKernelGGL(tables_kernel, dim3(S), dim3(256), 0, st, h->inv_freq, h->rot_freqs, pe, rc, rsn, S);
     LAUNCH_CHECK();
+    if (fuse_conv() && Sp > S) {      // the fused epilogue writes the S real rows of the v|u planes only
+        hipLaunchKernelGGL(zero_pad_rows_kernel, dim3(Sp - S, B), dim3(256), 0, st, vuP, S, Sp, 4L * HID);
+        LAUNCH_CHECK();
+    }
     unsigned* hdr = h->taps ? reinterpret_cast<unsigned*>(ws + P.hdr) : nullptr;       // [L][2] largest scaled |f16| of v|u and lin_k (tap "headroom")
     if (hdr) { hipLaunchKernelGGL(zero_words_kernel, dim3((2 * h->L + 255) / 256), dim3(256), 0, st, hdr, 2 * h->L); LAUNCH_CHECK(); }
     // ---- encoder + GroupNorm + 1x1 conv + positional encoding   (mossformer2.py:573, :487-496)
@@ -1090,8 +1128,13 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
             g.seg[0].a_shift = -1; g.seg[0].a_period = S; g.seg[0].a_zero = zrow;
             g.seg[1] = tdx::h3_seg(xp + 2 * C, xs + M, 4L * C, w.hWhq.p + 2 * C, w.hWhq.s, 4L * C, C / 2);
             g.nseg = 2; g.M = (int)M; g.N = HQ;
-            EpiHiddenSN<2, true> e{xss, M, S, 0.044194173824159216f, w.ghq, w.bhq, hid, HQ};       // (SiLU in conv17)
-            if (launch_linear_x3<true>(g, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+            if (fuse_conv()) {      // SiLU + depthwise conv of v|u in the epilogue: planes + fp32 u straight from the GEMM (H3Conv)
+                EpiHiddenConv e{xss, M, S, 0.044194173824159216f, w.ghq, w.bhq, hid, HQ, w.cw_h, vuP, w.sv_vu, vu, Sp};
+                if (tdx::launch_gemm_h3x<false, false, false, true>(g, 1, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+            } else {
+                EpiHiddenSN<2, true> e{xss, M, S, 0.044194173824159216f, w.ghq, w.bhq, hid, HQ};       // (SiLU in conv17)
+                if (launch_linear_x3<true>(g, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+            }
             if (prof) hipEventRecord(pe1, st);
         }
         // small forwards: the q/k-head branch (conv17<3> -> similarity) on the side stream, next to the v|u branch
@@ -1103,7 +1146,8 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
             Conv17Args a{};
             a.in = hid; a.ld_in = HQ; a.col0 = 0; a.wT = w.cw_h; a.C = HID; a.out = vu; a.out_c0 = HID / 2; a.ld_out = HID / 2; a.S = S; a.Sp = Sp;
             a.hp = vuP; a.sv = w.sv_vu; a.silu_in = 1;
-            TRY(launch_conv17<4>(a, B, st));          // v|u as K-major planes (GEMM operands; v also as the gate's operand) + u in fp32 (the gate's sigmoid)
+            if (!fuse_conv())
+                TRY(launch_conv17<4>(a, B, st));      // v|u as K-major planes (GEMM operands; v also as the gate's operand) + u in fp32 (the gate's sigmoid)
             Conv17Args q{};
             q.in = hid; q.ld_in = HQ; q.col0 = HID; q.wT = w.cw_qk; q.C = QK; q.S = S; q.Sp = Sp; q.gamma = w.gamma; q.beta = w.beta;
             q.rot_cos = rc; q.rot_sin = rsn; q.head_stride = (long)B * Sp * QK;

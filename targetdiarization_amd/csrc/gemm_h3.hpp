@@ -1253,6 +1253,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
 #pragma unroll
             for (int t = 0; t < KT; ++t) w[t] = *reinterpret_cast<const v2f*>(cv.w + (long)t * cv.wld + colp);
             __syncthreads();
+            H3_STAMP(tn == 0 ? 3 : 6);               // (diagnostic builds: phase 1 of this half done)
             const float* const Tc = T + 2 * lane;
             // per-lane byte offsets inside a planes row / an fp32 row; the row bases are wave-uniform (scalar + 32-bit offset stores)
             const unsigned poff = (unsigned)((colp >> 5) * 128 + (colp & 31) * 2);
@@ -1309,6 +1310,7 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
         };
         if (g.dbg & 32) return;                      // (timing: no conv epilogue at all)
         half(std::integral_constant<int, 0>{});
+        H3_STAMP(5);                                 // (wave 0's convolution of the first half done)
         __syncthreads();                             // the convolution of the first half has read T
         half(std::integral_constant<int, 1>{});
         }

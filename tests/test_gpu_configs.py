@@ -97,7 +97,7 @@ def test_30s_utterance_full_depth_pipeline(gold, hp24):
     for i, s in enumerate((a, b)):
         e = eo.eres2netv2_forward(fo.sv_features(torch.from_numpy(s[:80000]).double())[None], spk64)[0].numpy()
         got = hp24.spk.get_speaker_embedding(s[:80000])
-        assert rel(got, e) < 1e-3
+        assert rel(got, e) < 1e-4                                  # the north-star tolerance (F = 498 here; F = 998: tests/test_gpu_eres2net.py)
         assert abs(res["scores"][i] - orc.cosine_similarity(res["embeddings"][i], tgt)) < 1e-5
     # H3: one 30 s segment per stream -> 500 LFR frames
     assert [e.shape for e in res["encoder"]] == [(500, 512), (500, 512)]
@@ -191,3 +191,20 @@ def test_large_launch_equals_smaller_launches(sep24):
     for i in (0, 59):
         one = sep24(x[i:i + 1])
         assert float((big[i:i + 1] - one).abs().max()) <= 1e-5 * m
+
+
+def test_launch_of_100_windows_crosses_2_32_elements(sep24):
+    """bench.py's default is 90 windows of 10 s per launch sequence and --windows-per-launch is the caller's: from 99 windows on the
+    to_hidden / to_qk buffers pass 2^32 ELEMENTS (row index x 2176) and the v|u planes 2^34 bytes.  One launch sequence of 100 windows
+    (2.0 M token rows, 109 GiB workspace) against launches of their own for the first, a middle and the last two windows."""
+    g = torch.Generator().manual_seed(12)
+    x = (torch.randn(100, 160000, generator=g) * 0.1).cuda()
+    big = sep24(x)
+    assert big.shape == (100, 2, 160000) and bool(torch.isfinite(big).all())
+    m = float(big.abs().max())
+    for i in (0, 49, 98, 99):
+        one = sep24(x[i:i + 1])
+        d = float((big[i:i + 1] - one).abs().max())
+        assert d <= 1e-5 * m, (i, d, m)
+    del big
+    torch.cuda.empty_cache()

@@ -38,6 +38,23 @@ def test_embedding_from_features_vs_oracle(model_and_sd):
         assert rel_l2(out, ref) < 1e-4 and cosd(out, ref) < 1e-3, (B, F, rel_l2(out, ref))
 
 
+def test_embedding_at_the_benchmark_size_vs_oracle(model_and_sd):
+    """F = 998 (one 10 s window: the size BASELINE configs[2] / [3] embed at), B = 2 with different content, against the fp64 oracle
+    at the north-star tolerance; the second row also checks batch independence against a B = 1 call"""
+    from oracle import eres2netv2_oracle as eo
+    model, sd64 = model_and_sd
+    g = torch.Generator().manual_seed(998)
+    feat = torch.randn(2, 998, 80, generator=g) * 2.0
+    feat[1] = feat[1] * 0.3 + 1.5 * torch.sin(torch.arange(998)[:, None] / 37.0)          # another level and a slow trend
+    ref = eo.eres2netv2_forward(feat.double(), sd64)
+    out = model.embed_features(feat.to(dev))
+    assert out.shape == (2, 192)
+    for b in range(2):
+        assert rel_l2(out[b], ref[b]) < 1e-4 and cosd(out[b], ref[b]) < 1e-3, (b, rel_l2(out[b], ref[b]))
+    one = model.embed_features(feat[1:2].to(dev))
+    assert rel_l2(one[0], out[1]) < 1e-5
+
+
 def test_wave_to_embedding_and_cosine(model_and_sd, sd2):
     """wav -> fbank(povey) - mean -> ERes2NetV2, plus the cosine scorer, vs the chained oracles."""
     from oracle import eres2netv2_oracle as eo

@@ -65,5 +65,28 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def check_isa(force: bool = False, verbose: bool = False) -> None:
+    """The inline-asm `ds_read_b64_tr_b16` reads (csrc/gemm_h3.hpp h3_tr_read) sit outside the compiler's lgkmcnt bookkeeping: after every
+    (re)build the generated gfx950 ISA of mf2.hip is scanned for an instruction that reads their destination registers before the fence
+    (tools/asm_tr_hazard.py) — a compiler bump would otherwise change the hazard window silently.  Cached by a stamp file."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(CSRC, "mf2.hip")
+    stamp = os.path.join(OBJ, "isa_checked.stamp")
+    tool = os.path.join(root, "tools", "asm_tr_hazard.py")
+    if not force and not _newer(stamp, [src, tool] + _deps()):
+        return
+    asm = os.path.join(OBJ, "mf2_isa.s")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "--cuda-device-only", "-S", "-o", asm, src]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=CSRC, capture_output=True)
+    r = subprocess.run([sys.executable, tool, asm], capture_output=True, text=True)
+    os.remove(asm)
+    if r.returncode != 0:
+        raise RuntimeError("ISA hazard scan failed (an instruction reads an asm ds_read_b64_tr_b16 destination before its fence):\n" + r.stdout + r.stderr)
+    open(stamp, "w").write(r.stdout)
+
+
 if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv, verbose=True))
+    check_isa(force="--force" in sys.argv, verbose=True)

@@ -156,6 +156,32 @@ int tdx_stft_inverse(tdx_stft* h, const float* spec_dev, int R, float* y_dev, vo
                      size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * N3  MDX-Net denoiser body — replaces `self.mdx_model.run(None, {"input": mix_spec})[0]`  AudioProcessor.py:630
+ *     (an onnxruntime session over UVR-MDX-NET-*.onnx, AudioProcessor.py:224-241: third-party; the network is KUIELab's
+ *     ConvTDFNet / TFC-TDF v2: first 1x1 conv, n = num_blocks/2 encoder levels of [l x (3x3 conv + BN + ReLU) + TDF bottleneck
+ *     Linear pair over frequency] with 2x2 stride-2 down convs, bottleneck block, n decoder levels with 2x2 transposed convs and
+ *     multiplicative skips, final 1x1 conv).  blob: TDXW container with the PyTorch module names of that class (first_conv.*,
+ *     encoding_blocks.{i}.tfc.H.{j}.*, encoding_blocks.{i}.tdf.*, ds.{i}.*, bottleneck_block.*, us.{i}.*, decoding_blocks.{i}.*,
+ *     final_conv.*), BatchNorm2d in eval mode.  spec_dev [B,4,dim_f,dim_t] (tdx_stft_forward output) -> out_dev, same shape.
+ * ---------------------------------------------------------------------------------- */
+typedef struct tdx_mdx tdx_mdx;
+typedef struct tdx_mdx_config {
+    int32_t num_blocks;   /* L = 11 (AudioProcessor.py:241) */
+    int32_t l;            /* convolutions per TFC block (3) */
+    int32_t g;            /* channel growth per level (32; multiple of 32) */
+    int32_t k;            /* TFC kernel size; must be 3 */
+    int32_t bn;           /* TDF bottleneck factor (8) */
+    int32_t dim_f;        /* 3072 */
+    int32_t dim_t;        /* frames per block: 256 (the reference passes dim_t = 8 meaning 2^8) */
+    int32_t reserved;
+} tdx_mdx_config;
+int tdx_mdx_create(const tdx_mdx_config* cfg, const void* weights_blob, size_t blob_bytes, int device, tdx_mdx** out);
+int tdx_mdx_destroy(tdx_mdx* h);
+size_t tdx_mdx_workspace_bytes(const tdx_mdx* h, int B);
+double tdx_mdx_flops(const tdx_mdx* h, int B);
+int tdx_mdx_forward(tdx_mdx* h, const float* spec_dev, int B, float* out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * a12 Paraformer-large SANM encoder — replaces the encoder forward inside
  *     `self.asr['paraformer'].generate(input=wav, hotword=...)`  ASRProcessor.py:424
  *     (funasr SANMEncoder: third-party; 1+49 pre-LN layers, d=512, 4 heads, FSMN memory k=11).

@@ -18,6 +18,11 @@ class Mf2Config(C.Structure):
                 ("num_spks", C.c_int32), ("group_size", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
+class MdxConfig(C.Structure):
+    _fields_ = [("num_blocks", C.c_int32), ("l", C.c_int32), ("g", C.c_int32), ("k", C.c_int32), ("bn", C.c_int32),
+                ("dim_f", C.c_int32), ("dim_t", C.c_int32), ("reserved", C.c_int32)]
+
+
 _lib = None
 
 # every symbol include/tdx.h declares: (restype, argtypes)
@@ -51,6 +56,11 @@ SIGNATURES = {
     "tdx_stft_workspace_bytes": (_sz, [_vp, _i]),
     "tdx_stft_forward": (_i, [_vp, _fp, _i, _fp, _vp, _sz, _vp]),
     "tdx_stft_inverse": (_i, [_vp, _fp, _i, _fp, _vp, _sz, _vp]),
+    "tdx_mdx_create": (_i, [C.POINTER(MdxConfig), _vp, _sz, _i, C.POINTER(_vp)]),
+    "tdx_mdx_destroy": (_i, [_vp]),
+    "tdx_mdx_workspace_bytes": (_sz, [_vp, _i]),
+    "tdx_mdx_flops": (C.c_double, [_vp, _i]),
+    "tdx_mdx_forward": (_i, [_vp, _fp, _i, _fp, _vp, _sz, _vp]),
     "tdx_pfenc_create": (_i, [_i, _vp, _sz, _i, C.POINTER(_vp)]),
     "tdx_pfenc_destroy": (_i, [_vp]),
     "tdx_pfenc_workspace_bytes": (_sz, [_vp, _i, _i]),

@@ -7,7 +7,8 @@ batch = 1), on the MI355X-native MossFormer2 (libtdx.so).
 
 `denoise_vocal` (:601-713) keeps the reference's outer 15 s / 1 s-margin chunker and the block plan of
 `process_audio_chunk` (:605-643) around the device STFT / iSTFT (`frontend.BlockSTFT` = ConvTDFNet.stft/.istft
-:82-120); the MDX net BODY is a third-party ONNX model (no weights, no onnxruntime here) and therefore a plug-in
+:82-120); the MDX net BODY (a third-party ONNX model in the reference: no weights, no onnxruntime here) is either the device
+implementation of its architecture (`mdx_state_dict` -> `mdx.ConvTDFNetBody`, csrc/mdx.hip; parity unpinned) or any plug-in
 `mdx_model(spec[n,4,dim_f,dim_t]) -> spec` on device tensors.  Resampling runs on the device polyphase resampler
 (`ops.resample_poly`; the reference calls librosa: parity unpinned).
 
@@ -33,7 +34,8 @@ class AudioProcessor:
                  is_separate_audio: bool = False, separater_weights_folder: str = "look2hear/checkpoints/TFGNet-Noise",
                  is_restore_audio: bool = False, restorer_weights_folder: str = "JusperLee/Apollo",
                  verbose_log: bool = True, cuda_device: int = 0, quality: int = 2,
-                 separater_state_dict=None, mdx_model=None, mdx_dim_f: int = 3072, mdx_n_fft: int = 6144, silero_vad=None):
+                 separater_state_dict=None, mdx_model=None, mdx_dim_f: int = 3072, mdx_n_fft: int = 6144, silero_vad=None,
+                 mdx_state_dict=None, mdx_args=None):
         """`separater_state_dict` (extension): an in-memory state_dict instead of
         `<separater_weights_folder>/best_model.pth` — no checkpoint ships with the reference.
         `mdx_model` (extension): the MDX net body as a callable on device tensors, spec[n,4,dim_f,256] -> spec (the

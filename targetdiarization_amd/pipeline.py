@@ -61,11 +61,13 @@ def gather_embeddings(local: torch.Tensor, n_total: int, rank: int, world: int, 
 class HotPath:
     def __init__(self, sep_state_dict, spk_state_dict=None, asr_state_dict=None, cuda_device: int = 0,
                  asr_segment: int = 480000, cmvn_shift=None, cmvn_scale=None, windows_per_launch: int = 32,
-                 asr_rows_per_launch: int = 32768, mdx_model=None, mdx_weights_file: str = "mdx/weights/UVR-MDX-NET-Inst_HQ_3.onnx"):
+                 asr_rows_per_launch: int = 32768, mdx_model=None, mdx_weights_file: str = "mdx/weights/UVR-MDX-NET-Inst_HQ_3.onnx",
+                 mdx_state_dict=None, mdx_args=None):
         from .audio_processor import AudioProcessor
         self.device = torch.device(f"cuda:{cuda_device}")
         self.ap = AudioProcessor(is_separate_audio=True, separater_state_dict=sep_state_dict, cuda_device=cuda_device, verbose_log=False,
-                                 is_denoise_vocal=mdx_model is not None, mdx_model=mdx_model, mdx_weights_file=mdx_weights_file, quality=3)
+                                 is_denoise_vocal=mdx_model is not None or mdx_state_dict is not None, mdx_model=mdx_model,
+                                 mdx_weights_file=mdx_weights_file, quality=3, mdx_state_dict=mdx_state_dict, mdx_args=mdx_args)
         if not self.ap.is_separate_audio:
             from ._lib import TdxError
             raise TdxError("separator failed to initialise")

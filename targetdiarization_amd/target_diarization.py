@@ -13,8 +13,8 @@ order of its steps, with two differences that are the point of the rewrite:
       decoder(encoder_out[T',512]) -> (text, [(token, [s, e]), ...][, language])   (CIF + NAR decoder)
       punctuation(text)  -> text                                          (CT-Transformer, ASRProcessor.py:880-897)
     Defaults: one segment per utterance / no overlap detector / whole clip is speech / the device decoder / text unchanged.
-Denoising (MDX net body), Apollo restoration, resampling and file decoding are outside the
-path: inputs are 16 kHz mono float arrays.
+The MDX denoiser body runs on the device when `mdx_state_dict` is given (mdx.ConvTDFNetBody, or any `mdx_model` callable); Apollo
+restoration and non-.wav file decoding are outside the path.
 """
 from __future__ import annotations
 
@@ -45,7 +45,7 @@ class TargetDiarization:
                  sep_state_dict=None, spk_state_dict=None, asr_state_dict=None,
                  sd_pipeline: Optional[Callable] = None, od_pipeline: Optional[Callable] = None,
                  vad: Optional[Callable] = None, decoder: Optional[Callable] = None, mdx_model: Optional[Callable] = None, token_list=None,
-                 punctuation: Optional[Callable] = None, **kwargs):
+                 punctuation: Optional[Callable] = None, mdx_state_dict=None, mdx_args=None, **kwargs):
         self.target_similarity_threshold = target_similarity_threshold
         self.asr_engine = asr_engine
         self.cuda_device = cuda_device
@@ -57,7 +57,7 @@ class TargetDiarization:
         self.token_list = token_list          # funasr's tokens.json (absent here): ids -> text; None -> "<id>" placeholders
         self.punctuation = punctuation        # CT-Transformer punctuation restorer (ASRProcessor.punctuation_restore :880-897, third-party): text -> text
         self.hp = HotPath(sep_state_dict, spk_state_dict, asr_state_dict, cuda_device=cuda_device, mdx_model=mdx_model,
-                          mdx_weights_file=mdx_weights_file)
+                          mdx_weights_file=mdx_weights_file, mdx_state_dict=mdx_state_dict, mdx_args=mdx_args)
         # One model serves every request of the reference's server (main.py:42): REST handlers and WebSocket worker threads call
         # into it concurrently.  Each model object of the hot path serialises its own calls (_lib.HandleGuard); this lock keeps a
         # whole infer() — and, in stream mode, the processing of one released buffer — together, so that concurrent requests

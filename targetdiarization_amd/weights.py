@@ -341,3 +341,69 @@ def pack_blob(state_dict) -> bytes:
         body += dbytes
         body += b"\0" * ((-len(dbytes)) % 64)
     return bytes(head) + bytes(body)
+
+
+# ---------------------------------------------------------------------------------------
+# MDX-Net denoiser body (KUIELab ConvTDFNet / TFC-TDF v2; the network inside the UVR-MDX-NET *.onnx files that
+# AudioProcessor.init_mdx_model hands to onnxruntime, AudioProcessor.py:224-241).  [upstream-recall]: module tree of
+# kuielab/mdx-net `ConvTDFNet` (first_conv, encoding_blocks.{i}.{tfc.H.{j}, tdf}, ds.{i}, bottleneck_block, us.{i},
+# decoding_blocks.{i}, final_conv), BatchNorm2d norms (the rmsprop-trained public models), no checkpoint in the reference tree.
+# ---------------------------------------------------------------------------------------
+def mdx_param_shapes(L: int = 11, l: int = 3, g: int = 32, k: int = 3, bn: int = 8, bias: bool = False, dim_c: int = 4,
+                     dim_f: int = 3072) -> "OrderedDict[str, tuple]":
+    s = OrderedDict()
+    n = L // 2
+
+    def norm(p, c):
+        s[p + "weight"] = (c,); s[p + "bias"] = (c,); s[p + "running_mean"] = (c,); s[p + "running_var"] = (c,)
+
+    def tfc_tdf(p, c, f):
+        for j in range(l):
+            s[f"{p}tfc.H.{j}.0.weight"] = (c, c, k, k); s[f"{p}tfc.H.{j}.0.bias"] = (c,)
+            norm(f"{p}tfc.H.{j}.1.", c)
+        s[p + "tdf.0.weight"] = (f // bn, f)
+        if bias:
+            s[p + "tdf.0.bias"] = (f // bn,)
+        norm(p + "tdf.1.", c)
+        s[p + "tdf.3.weight"] = (f, f // bn)
+        if bias:
+            s[p + "tdf.3.bias"] = (f,)
+        norm(p + "tdf.4.", c)
+    s["first_conv.0.weight"] = (g, dim_c, 1, 1); s["first_conv.0.bias"] = (g,)
+    norm("first_conv.1.", g)
+    f, c = dim_f, g
+    for i in range(n):
+        tfc_tdf(f"encoding_blocks.{i}.", c, f)
+        s[f"ds.{i}.0.weight"] = (c + g, c, 2, 2); s[f"ds.{i}.0.bias"] = (c + g,)
+        norm(f"ds.{i}.1.", c + g)
+        f //= 2; c += g
+    tfc_tdf("bottleneck_block.", c, f)
+    for i in range(n):
+        s[f"us.{i}.0.weight"] = (c, c - g, 2, 2); s[f"us.{i}.0.bias"] = (c - g,)      # ConvTranspose2d: [in, out, kh, kw]
+        norm(f"us.{i}.1.", c - g)
+        f *= 2; c -= g
+        tfc_tdf(f"decoding_blocks.{i}.", c, f)
+    s["final_conv.0.weight"] = (dim_c, c, 1, 1); s["final_conv.0.bias"] = (dim_c,)
+    return s
+
+
+def recipe_mdx_state_dict(seed: int = 0, **kw) -> "OrderedDict[str, torch.Tensor]":
+    out = OrderedDict()
+    for name, shape in mdx_param_shapes(**kw).items():
+        u = torch.from_numpy(philox_uniform("mdx:" + name, int(np.prod(shape)), seed)).reshape(shape)
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf == "running_var":
+            t = 1.0 + 0.3 * u
+        elif leaf == "running_mean":
+            t = 0.1 * u
+        elif len(shape) == 1 and leaf == "weight":
+            t = 1.0 + 0.2 * u                      # BatchNorm gamma
+        elif leaf == "bias":
+            t = 0.1 * u
+        elif name.startswith("us."):               # ConvTranspose2d [in, out, 2, 2]: every output pixel sees `in` inputs
+            t = u * float(np.sqrt(3.0 / shape[0]))
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            t = u * float(np.sqrt(3.0 / fan_in))    # keeps the activations O(1) through the ~35 layers (x + tdf(x), x * skip included)
+        out[name] = t.to(torch.float32).contiguous()
+    return out

@@ -24,9 +24,9 @@ int tdx_h3_gemm_x(int mode, const void* pa, const float* sa, const void* pb, con
 int tdx_h3_gemm(const void* pa, const float* sa, const void* pb, const float* sb, const float* bias_dev, float* c_dev,
                 int M, int N, int K, void* stream);
 /* timing variants of the x3 main loop (gemm_h3.hpp VARIANT: 0 product, 1 no loads, 2 no fragment reads, 3 neither,
- * 4 no barrier, 5 ping-pong, 6 v_mfma_f32_16x16x32_f16 instead of 32x32x16 (same flops), 9 loads never waited for;
- * 10 = the narrow kernel gemm_h3n.hpp (256 x 128 tile, two blocks per CU), 16 = narrow + 16x16x32 (timing only),
- * 20 = the pair-stage kernel gemm_h3p.hpp (16x16x32 MFMA, correct results)); only 0, 5, 10 and 20 produce correct results */
+ * 4 no barrier, 5 ping-pong, 6 v_mfma_f32_16x16x32_f16 instead of 32x32x16 (same flops), 9 loads never waited for); only 0 and 5
+ * produce correct results.  (The narrow two-blocks-per-CU kernel and the pair-stage 16x16x32 kernel of round 2 — variants 10 / 16 /
+ * 20 — lost inside the model and were removed in round 3; their measurements are in DESIGN.md §4.1e.) */
 int tdx_h3_gemm_variant(const void* pa, const float* sa, const void* pb, const float* sb, const float* bias_dev,
                         float* c_dev, int M, int N, int K, int variant, void* stream);
 /* timing variants of the fp32-MFMA core (gemm.hpp VARIANT) and the x6 core (variant 6) */

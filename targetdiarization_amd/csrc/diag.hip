@@ -10,8 +10,6 @@
 #include "gemm.hpp"
 #include "gemm_x6.hpp"
 #include "gemm_h3.hpp"
-#include "gemm_h3n.hpp"
-#include "gemm_h3p.hpp"
 #include "tdx_common.hpp"
 
 using namespace tdx;
@@ -94,9 +92,6 @@ int tdx_h3_gemm_variant(const void* pa, const float* sa, const void* pb, const f
     else if (variant == 9) r = tdx::launch_gemm_h3<false, EpiBias, 9>(g, 1, e, (hipStream_t)stream);
     else if (variant == 5) r = tdx::launch_gemm_h3<false, EpiBias, 5>(g, 1, e, (hipStream_t)stream);
     else if (variant == 6) r = tdx::launch_gemm_h3<false, EpiBias, 6>(g, 1, e, (hipStream_t)stream);
-    else if (variant == 10) r = tdx::launch_gemm_h3n<false, EpiBias, 0>(g, 1, e, (hipStream_t)stream);      // narrow tile, two blocks per CU (correct results)
-    else if (variant == 20) r = tdx::launch_gemm_h3p<false, EpiBias>(g, 1, e, (hipStream_t)stream);         // pair-stage kernel, 16x16x32 MFMA (correct results)
-    else if (variant == 16) r = tdx::launch_gemm_h3n<false, EpiBias, 1>(g, 1, e, (hipStream_t)stream);      // ... with the 16x16x32 MFMA shape (timing only)
     else r = tdx::launch_gemm_h3<false, EpiBias, 0>(g, 1, e, (hipStream_t)stream);
     return r == hipSuccess ? TDX_OK : tdx::fail_hip(r, __FILE__, __LINE__);
 }

@@ -21,7 +21,6 @@
 #include "gemm_x6.hpp"
 #include "gemm_h3.hpp"
 #include "gemm_h3a.hpp"
-#include "gemm_h3p.hpp"
 #include "mf2_kernels.hpp"
 #include "tdx_common.hpp"
 
@@ -713,14 +712,6 @@ int linear_gemm_f32(const float* A, long lda, const float* W, int M, int N, int 
 
 #define TRY(x) do { int rc__ = (x); if (rc__ != TDX_OK) return rc__; } while (0)
 
-// A/B switch for the pair-stage kernel (gemm_h3p.hpp: v_mfma_f32_16x16x32_f16) on the two largest row-major Linear launches.
-// Measured: 3-6 % faster than the 32x32x16 kernel stand-alone on random data, but 10 % SLOWER inside the
-// model (to_hidden 1.94 vs 1.76 ms) — its ring holds only one pair of look-ahead.  Default off; TDX_H3P=1 enables it
-// (same results up to the accumulation order; the parity suite passes either way).
-inline bool use_h3p() {
-    static const bool on = [] { const char* e = getenv("TDX_H3P"); return e ? atoi(e) != 0 : false; }();
-    return on;
-}
 // A/B switch: the depthwise convolution of v|u fused into the to_hidden epilogue (gemm_h3.hpp H3Conv).  TDX_FUSE_CONV=0 restores the
 // separate conv17<4> pass (same arithmetic in the same order: bit-identical results).
 inline bool fuse_conv() {
@@ -729,7 +720,6 @@ inline bool fuse_conv() {
 }
 template <bool TWOSEG, class Epi>
 hipError_t launch_linear_x3(tdx::H3Args g, Epi e, hipStream_t st) {
-    if (use_h3p()) return tdx::launch_gemm_h3p<TWOSEG, Epi>(g, 1, e, st);
     return tdx::launch_gemm_h3x<false, false, false, TWOSEG>(g, 1, e, st);
 }
 

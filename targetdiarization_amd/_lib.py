@@ -61,6 +61,10 @@ SIGNATURES = {
     "tdx_mdx_workspace_bytes": (_sz, [_vp, _i]),
     "tdx_mdx_flops": (C.c_double, [_vp, _i]),
     "tdx_mdx_forward": (_i, [_vp, _fp, _i, _fp, _vp, _sz, _vp]),
+    "tdx_punc_create": (_i, [_i, _i, _i, _vp, _sz, _i, C.POINTER(_vp)]),
+    "tdx_punc_destroy": (_i, [_vp]),
+    "tdx_punc_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "tdx_punc_forward": (_i, [_vp, _vp, _i, _i, _fp, _vp, _sz, _vp]),
     "tdx_pfenc_create": (_i, [_i, _vp, _sz, _i, C.POINTER(_vp)]),
     "tdx_pfenc_destroy": (_i, [_vp]),
     "tdx_pfenc_workspace_bytes": (_sz, [_vp, _i, _i]),

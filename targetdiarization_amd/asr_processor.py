@@ -18,11 +18,19 @@ class ASRProcessor:
                  is_punc: bool = False, punc_model_dir: str = "", is_timestamp: bool = False, timestamp_model_dir: str = "",
                  is_emotion: bool = False, emotion_model_dir: str = "", is_diarization: bool = False, diarization_model_dir: str = "",
                  is_asr_api: bool = False, api_config_path: str = "", verbose_log: bool = True, cuda_device: int = 0, ap=None,
-                 *, asr_state_dict=None, decoder: Optional[Callable] = None, punctuation: Optional[Callable] = None, token_list=None):
+                 *, asr_state_dict=None, decoder: Optional[Callable] = None, punctuation: Optional[Callable] = None, token_list=None,
+                 punc_state_dict=None, punc_vocab=None):
         self.is_asr = is_asr
         self.verbose_log = verbose_log
         self.decoder = decoder
         self.punctuation = punctuation
+        if punctuation is None and punc_state_dict is not None:      # ASRProcessor.py:261-268: load, or print and switch the feature off
+            try:
+                from .punctuation import CTTransformer
+                self.punctuation = CTTransformer(punc_state_dict, device=f"cuda:{cuda_device}", vocab=punc_vocab)
+            except Exception as e:
+                print(f"Failed to load punctuation restorer model: {e}")
+        self.is_punc = self.punctuation is not None
         self.token_list = token_list
         self.asr = {}
         self.nar_decoder = None
@@ -44,8 +52,21 @@ class ASRProcessor:
         toks = [self.token_list[i] if self.token_list is not None and i < len(self.token_list) else f"<{i}>" for i in r["token_ids"]]
         return {"text": " ".join(toks), "timestamp": r["timestamp"], "token_ids": r["token_ids"]}
 
-    def punctuation_restore(self, text: str) -> str:
-        return self.punctuation(text) if self.punctuation is not None else text
+    def punctuation_restore(self, text):
+        """ASRProcessor.punctuation_restore (:880-897): str or list of str; no model / empty text / a failing model -> the text unchanged"""
+        if self.punctuation is None:
+            if self.verbose_log:
+                print("Modelscope punctuation restorer model hasn't been loaded. Return original result.")
+            return text
+        if not text:
+            return text
+        try:
+            if isinstance(text, str):
+                return self.punctuation(text)
+            return [self.punctuation(t) if t else t for t in text]
+        except Exception as e:
+            print(f"Failed in punctuation_restore: {e}")
+            return text
 
     @staticmethod
     def detect_language(text: str) -> str:

@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libtdx.so")
 LIB_DIAG = os.path.join(HERE, "libtdx_diag.so")
-SOURCES = ["mf2.hip", "frontend.hip", "paraformer.hip", "eres2net.hip", "mdx.hip"]
+SOURCES = ["mf2.hip", "frontend.hip", "paraformer.hip", "eres2net.hip", "mdx.hip", "punc.hip"]
 DIAG_SOURCES = ["diag.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]

@@ -45,7 +45,8 @@ class TargetDiarization:
                  sep_state_dict=None, spk_state_dict=None, asr_state_dict=None,
                  sd_pipeline: Optional[Callable] = None, od_pipeline: Optional[Callable] = None,
                  vad: Optional[Callable] = None, decoder: Optional[Callable] = None, mdx_model: Optional[Callable] = None, token_list=None,
-                 punctuation: Optional[Callable] = None, mdx_state_dict=None, mdx_args=None, **kwargs):
+                 punctuation: Optional[Callable] = None, mdx_state_dict=None, mdx_args=None,
+                 punc_state_dict=None, punc_vocab=None, **kwargs):
         self.target_similarity_threshold = target_similarity_threshold
         self.asr_engine = asr_engine
         self.cuda_device = cuda_device
@@ -56,6 +57,9 @@ class TargetDiarization:
         self.decoder = decoder
         self.token_list = token_list          # funasr's tokens.json (absent here): ids -> text; None -> "<id>" placeholders
         self.punctuation = punctuation        # CT-Transformer punctuation restorer (ASRProcessor.punctuation_restore :880-897, third-party): text -> text
+        if punctuation is None and punc_state_dict is not None:      # the device CT-Transformer (punctuation.py, tdx_punc_*)
+            from .punctuation import CTTransformer
+            self.punctuation = CTTransformer(punc_state_dict, device=f"cuda:{cuda_device}", vocab=punc_vocab)
         self.hp = HotPath(sep_state_dict, spk_state_dict, asr_state_dict, cuda_device=cuda_device, mdx_model=mdx_model,
                           mdx_weights_file=mdx_weights_file, mdx_state_dict=mdx_state_dict, mdx_args=mdx_args)
         # One model serves every request of the reference's server (main.py:42): REST handlers and WebSocket worker threads call

@@ -407,3 +407,45 @@ def recipe_mdx_state_dict(seed: int = 0, **kw) -> "OrderedDict[str, torch.Tensor
             t = u * float(np.sqrt(3.0 / fan_in))    # keeps the activations O(1) through the ~35 layers (x + tdf(x), x * skip included)
         out[name] = t.to(torch.float32).contiguous()
     return out
+
+
+# ---------------------------------------------------------------------------------------
+# CT-Transformer punctuation model (funasr CTTransformer: Embedding -> SANM encoder -> Linear) [upstream-recall]
+# ---------------------------------------------------------------------------------------
+def punc_param_shapes(num_blocks: int = 4, vocab: int = 272727, npunc: int = 6, d: int = 256, ffn: int = 1024, ksize: int = 11) -> "OrderedDict[str, tuple]":
+    s = OrderedDict()
+    s["embed.weight"] = (vocab, d)
+
+    def layer(p):
+        s[p + "self_attn.linear_q_k_v.weight"] = (3 * d, d); s[p + "self_attn.linear_q_k_v.bias"] = (3 * d,)
+        s[p + "self_attn.fsmn_block.weight"] = (d, 1, ksize)
+        s[p + "self_attn.linear_out.weight"] = (d, d); s[p + "self_attn.linear_out.bias"] = (d,)
+        s[p + "feed_forward.w_1.weight"] = (ffn, d); s[p + "feed_forward.w_1.bias"] = (ffn,)
+        s[p + "feed_forward.w_2.weight"] = (d, ffn); s[p + "feed_forward.w_2.bias"] = (d,)
+        s[p + "norm1.weight"] = (d,); s[p + "norm1.bias"] = (d,); s[p + "norm2.weight"] = (d,); s[p + "norm2.bias"] = (d,)
+    layer("encoder.encoders0.0.")
+    for i in range(num_blocks - 1):
+        layer(f"encoder.encoders.{i}.")
+    s["encoder.after_norm.weight"] = (d,); s["encoder.after_norm.bias"] = (d,)
+    s["decoder.weight"] = (npunc, d); s["decoder.bias"] = (npunc,)
+    return s
+
+
+def recipe_punc_state_dict(seed: int = 0, num_blocks: int = 4, vocab: int = 4096, npunc: int = 6) -> "OrderedDict[str, torch.Tensor]":
+    """(a small vocabulary by default: the real table is 272 727 x 256 = 279 MB)"""
+    out = OrderedDict()
+    for name, shape in punc_param_shapes(num_blocks, vocab, npunc).items():
+        u = torch.from_numpy(philox_uniform("punc:" + name, int(np.prod(shape)), seed)).reshape(shape)
+        leaf = name.rsplit(".", 1)[-1]
+        if name == "embed.weight":
+            t = 0.5 * u
+        elif name.startswith("decoder."):
+            t = u * (2.0 if leaf == "weight" else 0.5)          # spread logits: every class gets chosen somewhere
+        elif ".norm" in name or "after_norm" in name:
+            t = (1.0 + 0.2 * u) if leaf == "weight" else 0.1 * u
+        elif leaf == "bias":
+            t = 0.1 * u
+        else:
+            t = u * float(1.0 / np.sqrt(int(np.prod(shape[1:]))))
+        out[name] = t.to(torch.float32).contiguous()
+    return out

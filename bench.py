@@ -55,8 +55,12 @@ H3_PASSES = 3                    # f16 MFMA passes per fp32-accurate product (cs
 PEAK_H3_TFLOPS = PEAK_F16_MFMA_TFLOPS / H3_PASSES
 DTYPE = "f32 (split-f16 x3: fp32-accurate products from three f16 MFMA passes, fp32 accumulate)"
 METRIC = "real-time factor (audio-sec/wall-sec) full infer() pipe, 16kHz mono, 1/2/4/8 GPU"
-KERNEL = ("gemm_h3_kernel<to_hidden+to_qk: split-f16 x3 MFMA over pre-split planes, ScaleNorm gain/bias epilogue "
-          "(SiLU applied by the consuming depthwise convolution)>")
+KERNEL = ("gemm_h3_kernel<TWOSEG, EpiHiddenConv> = to_hidden+to_qk: split-f16 x3 MFMA over pre-split planes; epilogue = ScaleNorm gain/bias, "
+          "SiLU and the 17-tap depthwise convolution of v|u, written as K-major planes + fp32 u (TDX_FUSE_CONV=0: the round-2 pair of launches)")
+FUSION_NOTE = ("since round 3 this launch also does the work of round 2's conv17<4> launch (SiLU + depthwise conv + split, VALU work in the epilogue, "
+               "+6.7 % MFMA work for the 16 halo rows per 256-row tile): `achieved` divides the GEMM's algorithmic FLOPs by the time of BOTH; "
+               "the two separate launches together ran 12.8 + 7.9 ms per 90-window launch of the default workload (profiles/r03_b_kernel_stats_cfg4_default_bench.csv) "
+               "= 194 TFLOP/s on the same definition (DESIGN 4.1g, 5)")
 WINDOW = 160000
 
 
@@ -373,7 +377,7 @@ def pipe_bench(args):
             "config": {"workload": desc, "audio_seconds_per_step": audio_s_per_step, "windows_per_launch": args.windows_per_launch,
                        "parallelism": f"{world} rank(s), one process per GPU, utterances sharded round-robin, full weight replica per rank"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_H3_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (ach / PEAK_H3_TFLOPS) if ach else None, "traffic": traffic, "kernel": KERNEL,
+                         "frac": (ach / PEAK_H3_TFLOPS) if ach else None, "traffic": traffic, "kernel": KERNEL, "fusion_note": FUSION_NOTE,
                          "peak_note": "algorithmic fp32-accurate FLOP/s ceiling of the kernel = dense f16 MFMA peak 2500 / 3 passes",
                          "mfma_pipe_executed_tflops": (ach * H3_PASSES) if ach else None,
                          "launches_timed": gemm_launches, "ms_per_launch": gemm_ms / max(gemm_launches, 1),
@@ -508,7 +512,7 @@ def cfg2_bench(args):
                        "per_gpu_batch": B, "samples_per_window": T, "frames_per_window": S,
                        "parallelism": f"{world} independent replicas (windows sharded, no collective)"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_H3_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (ach / PEAK_H3_TFLOPS) if ach else None, "traffic": traffic, "kernel": KERNEL,
+                         "frac": (ach / PEAK_H3_TFLOPS) if ach else None, "traffic": traffic, "kernel": KERNEL, "fusion_note": FUSION_NOTE,
                          "peak_note": "algorithmic fp32-accurate FLOP/s ceiling of the kernel = dense f16 MFMA peak 2500 / 3 passes",
                          "mfma_pipe_executed_tflops": (ach * H3_PASSES) if ach else None,
                          "launches_timed": gemm_launches, "ms_per_launch": gemm_ms / max(gemm_launches, 1),

@@ -4,10 +4,12 @@
 // feat [B,F,80] (fbank minus utterance mean, tdx_fbank mode 0) -> embedding [B,192].
 //
 // Layout: NHWC fp32, rows = (b, freq, time), channels contiguous and padded to a multiple of
-// 32.  Every convolution is an implicit GEMM on the fp32-MFMA core (gemm.hpp CONV mode: one
-// K segment per tap, the A-loader computes the shifted/strided input row and zero-fills the
-// halo), with eval-mode BatchNorm folded into the weights on the host and ReLU20 / residual /
-// Res2Net chain add / AFF gate fused into the epilogues.
+// 32.  The convolutions are implicit GEMMs (CONV mode: one K segment per tap, the A-loader computes the
+// shifted/strided input row and zero-fills the halo) — stage 1's 1x1 convolutions on the fp32-MFMA core (gemm.hpp),
+// stages 2-4 on the split-f16 x3 core (gemm_h3.hpp) over planes with a static scale (ReLU20-bounded activations) —
+// except the 3x3 chain convolutions of stages 1-2, which run on an LDS-tiled direct x3 convolution (chain_conv_x3_kernel).
+// Eval-mode BatchNorm is folded into the weights on the host; ReLU20 / residual / Res2Net chain add / AFF gate are
+// fused into the epilogues.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -171,89 +173,196 @@ struct EpiAffGate {     // att = 1 + tanh(v+b); out = x*att + y*(2-att), columns
 
 
 // ---------------------------------------------------------------------------------------------------------
-// Res2Net chain convolution of stage 1 (3x3, 24 -> 24 channels, stride 1) as an LDS-tiled DIRECT convolution.
-// As an implicit GEMM these launches re-read every input pixel nine times from L2 for 24 output columns of a
-// 128-wide tile; here a block stages the (8+2) x (32+2) pixel patch (24 channels, pixel pitch 28 floats:
-// conflict-free ds_read_b128 over consecutive pixels) and the 9 x 24 x 32 weights once and feeds
-// v_mfma_f32_32x32x2_f32 from LDS: wave w owns output rows 2w, 2w+1 of the tile (one 32-pixel row = one MFMA row
-// tile), 216 MFMAs per wave.  Epilogue = EpiChain.
+// Res2Net chain convolution of stages 1-2 (3x3, C -> C channels, stride 1, C = 24 / 48) as an LDS-tiled direct convolution on
+// the split-f16 x3 MFMA scheme.  As an implicit GEMM on the 256 x 256 tiles of gemm_h3.hpp these launches fill 48 of 256 tile
+// columns and re-read every input pixel nine times from L2 (stage 1 ran on a fp32-MFMA direct convolution until round 3); here
+// a block stages the (TH + 2) x 34 pixel patch ONCE, splitting the fp32 input into hi/lo f16 with the static scale 2^9 on the
+// way (inputs are sums of two ReLU20 outputs: no separate split pass, no planes in HBM), moves the weight planes one tap at a
+// time through a ring of register slots into a double-buffered LDS tile and feeds v_mfma_f32_32x32x16_f16 (3 passes:
+// hi.lo + lo.hi + hi.hi, the order of gemm_h3.hpp: results are bit-identical to the implicit GEMM) from LDS: wave w owns MT
+// image rows of 32 pixels (= 32-row MFMA tiles) and all NT 32-column tiles.  LDS images: [pixel | n][channel / 8][hi 16 B |
+// lo 16 B] with a pitch that is an odd multiple of 16 B (conflict-free ds_read_b128 over consecutive pixels / columns).
+// Epilogue = EpiChain.  Measured (B = 60, F = 998): C = 48: 422 us per launch (implicit GEMM 0.9 ms + 60 us split pass), of
+// which patch reads ~145, MFMA loop ~120, epilogue ~140 us, hardly overlapped — 1.26 GB per launch, the two memory phases each
+// run at 3.4-5.5 TB/s; C = 24 (TH = 4, four blocks per CU): 703 us for 2.5 GB (fp32-MFMA direct convolution: 1112 us).
+// With C = 96 (stage 3; 158 KB of LDS, one block per CU) the kernel lost to the implicit GEMM (0.50 vs 0.34 ms): not instantiated.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int DC_TH = 8, DC_TW = 32, DC_C = 24, DC_PP = 28;        // tile rows / cols, channels, LDS pixel pitch (floats)
-struct DirectConvArgs {
-    const float* in; long ldin;          // NHWC input [B*H*W][ldin], channels 0..23
-    const float* w;                      // folded weights as [9 taps][24 k][24 n] (ConvW::wd), bias b[n]
+struct ChainX3Args {
+    const float* in; long ldin;                         // NHWC input [B*H*W][ldin], channels 0..CIN-1
+    const unsigned char* wp; const float* ws; int wk;   // weight planes [n][wk / 8][2][8] f16 (wk = 9 * cinp), inverse row scales ws[n]
+    int cinp;
     const float* b;
-    float* cat; long ldcat; int coff;    // sp -> cat[m*ldcat + coff + n], n < 24
-    const float* o1; long ldo1; int next_off; float* spin;      // spin (or null): spin[m*32 + n] = n < 24 ? sp + o1[m*ldo1 + next_off + n] : 0
+    float* cat; long ldcat; int coff;                   // sp -> cat[m*ldcat + coff + n], n < CIN
+    const float* o1; long ldo1; int next_off; float* spin; int ldspin;      // spin (or null): spin[m*ldspin + n] = n < CIN ? sp + o1[m*ldo1 + next_off + n] : 0
     int H, W;
 };
-__global__ __launch_bounds__(256) void chain_conv24_kernel(DirectConvArgs a) {
-    __shared__ __attribute__((aligned(16))) float patch[(DC_TH + 2) * (DC_TW + 2) * DC_PP];
-    __shared__ __attribute__((aligned(16))) float wl[9 * DC_C * DC_C];          // [tap][k][n < 24]  (58.8 KB of LDS in all: two blocks per CU)
+template <int CIN, int TH>
+struct ChainX3Cfg {
+    static constexpr int KS = (CIN + 15) / 16, CP = KS * 16, PPB = CP * 4 + 16, NT = (CIN + 31) / 32, NB = NT * 32, MT = TH / 4;
+    static constexpr int PATCH = (TH + 2) * 34 * PPB, BT = NB * PPB, LDS = PATCH + 2 * BT;
+    static constexpr int BQ = NB * (CP / 8) * 2;         // 16-B pieces of one tap's weight tile
+    static constexpr int BPT = (BQ + 255) / 256;
+};
+template <int CIN, int TH>
+__global__ __launch_bounds__(256) void chain_conv_x3_kernel(ChainX3Args a) {
+    using C = ChainX3Cfg<CIN, TH>;
+    constexpr int KS = C::KS, CP = C::CP, PPB = C::PPB, NT = C::NT, MT = C::MT;
+    static_assert(PPB % 32 == 16 && TH % 4 == 0 && CIN % 4 == 0, "pitch = odd multiple of 16 B");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* const patch = lds;
+    unsigned char* const bt = lds + C::PATCH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-    const int x0 = blockIdx.x * DC_TW, y0 = blockIdx.y * DC_TH, b = blockIdx.z;
-    // ---- stage the input patch (zero outside the image) and the weights
-    for (int t = tid; t < (DC_TH + 2) * (DC_TW + 2) * (DC_C / 4); t += 256) {
-        const int p = t / (DC_C / 4), q = t - p * (DC_C / 4);
-        const int py = p / (DC_TW + 2), px = p - py * (DC_TW + 2);
-        const int iy = y0 + py - 1, ix = x0 + px - 1;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *reinterpret_cast<const float4*>(a.in + (((long)b * a.H + iy) * a.W + ix) * a.ldin + 4 * q);
-        *reinterpret_cast<float4*>(patch + p * DC_PP + 4 * q) = v;
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * TH, b = blockIdx.z;
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    // ---- weight tiles: global planes -> a ring of three register slots (16-B pieces (n, chunk, hi|lo)) -> the double-buffered LDS
+    // tile.  Tap t + 4 is requested in iteration t and written to LDS in iteration t + 3: no global latency inside the tap loop.
+    // (literal tap numbers, native vector type: the array stays in registers — HIP's uint4 struct is copied by memcpy, which
+    // kept it in scratch)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 breg[3][C::BPT];
+#define TDX_CHAIN_BLOAD(tap_)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < C::BPT; ++i) {                                                               \
+        const int t = tid + i * 256;                                                                                   \
+        if (C::BQ % 256 == 0 || t < C::BQ) {                                                                           \
+            const int n = t / (CP / 4), r = t - n * (CP / 4);       /* r = 2 * chunk + (lo ? 1 : 0) */                 \
+            breg[(tap_) % 3][i] = *reinterpret_cast<const u32x4*>(a.wp + (long)n * a.wk * 4 + ((long)(tap_) * a.cinp / 8) * 32 + r * 16); \
+        }                                                                                                              \
     }
-    for (int t = tid; t < 9 * DC_C * DC_C / 4; t += 256) *reinterpret_cast<float4*>(wl + 4 * t) = *reinterpret_cast<const float4*>(a.w + 4 * t);
-    __syncthreads();
-    f32x16 acc[2];
+#define TDX_CHAIN_BSTORE(tap_)                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < C::BPT; ++i) {                                                               \
+        const int t = tid + i * 256;                                                                                   \
+        if (C::BQ % 256 == 0 || t < C::BQ) {                                                                           \
+            const int n = t / (CP / 4), r = t - n * (CP / 4);                                                          \
+            *reinterpret_cast<u32x4*>(bt + ((tap_) & 1) * C::BT + n * PPB + r * 16) = breg[(tap_) % 3][i];             \
+        }                                                                                                              \
+    }
+    TDX_CHAIN_BLOAD(0) TDX_CHAIN_BLOAD(1) TDX_CHAIN_BLOAD(2)
+    // ---- the input patch (zero outside the image and for the channels >= CIN): every load of the thread in flight at once
+    constexpr int SLOTS = (TH + 2) * 34 * (CP / 4), SPT = (SLOTS + 255) / 256;
+    float4 sv[SPT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    for (int i = 0; i < SPT; ++i) {
+        const int t = tid + i * 256;
+        const int p = t / (CP / 4), q = t - p * (CP / 4);
+        const int py = p / 34, px = p - py * 34;
+        const int iy = y0 + py - 1, ix = x0 + px - 1;
+        sv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < SLOTS && 4 * q < CIN && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+            sv[i] = *reinterpret_cast<const float4*>(a.in + (((long)b * a.H + iy) * a.W + ix) * a.ldin + 4 * q);
+    }
+    // ---- the epilogue's operands (bias, scale, the next chunk of conv1's output) do not depend on the accumulators: requested now
+    float bias[NT], sc[NT], nx[NT][MT][16];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int dy = tap / 3, dx = tap - dy * 3;              // patch offsets (halo of one pixel already included)
+    for (int n = 0; n < NT; ++n) {
+        const int c = n * 32 + l31;
+        const bool real = c < CIN;
+        bias[n] = real ? a.b[c] : 0.f;
+        sc[n] = real ? a.ws[c] * (1.0f / 512.0f) : 0.f;
 #pragma unroll
-        for (int kc = 0; kc < 3; ++kc) {
-            const int k0 = 8 * kc + 4 * h;
-            float bv[4];
+        for (int m = 0; m < MT; ++m) {
+            const int y = min(y0 + MT * wave + m, a.H - 1);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = wl[(tap * DC_C + k0 + j) * DC_C + min(l31, DC_C - 1)];      // columns >= 24 are never stored
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(patch + ((2 * wave + r + dy) * (DC_TW + 2) + l31 + dx) * DC_PP + k0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[r], 0, 0, 0);
+            for (int i = 0; i < 16; ++i) {
+                const int x = min(x0 + (i & 3) + 8 * (i >> 2) + 4 * h, a.W - 1);
+                nx[n][m][i] = (a.spin && real) ? a.o1[(((long)b * a.H + y) * a.W + x) * a.ldo1 + a.next_off + c] : 0.f;
             }
         }
     }
-    // ---- epilogue (EpiChain): D col = l31 (output channel), row = (r&3) + 8*(r>>2) + 4*h (pixel of the row)
-    // (touch(): loaded values are waited for in straight-line code before the conditional stores, see gemm.hpp)
-    float bias = l31 < DC_C ? a.b[l31] : 0.f;
-    tdx::touch(bias);
+    // ---- split the patch with the static scale 2^9 into the LDS image
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int y = y0 + 2 * wave + r;
-        if (y >= a.H) continue;
-        float nx[16];
+    for (int i = 0; i < SPT; ++i) {
+        const int t = tid + i * 256;
+        const int p = t / (CP / 4), q = t - p * (CP / 4);
+        const float xs[4] = {sv[i].x * 512.0f, sv[i].y * 512.0f, sv[i].z * 512.0f, sv[i].w * 512.0f};
+        h4 hi, lo;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int x = min(x0 + (i & 3) + 8 * (i >> 2) + 4 * h, a.W - 1);
-            nx[i] = (a.spin && l31 < DC_C) ? a.o1[(((long)b * a.H + y) * a.W + x) * a.ldo1 + a.next_off + l31] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) tdx::touch(nx[i]);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int x = x0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (x >= a.W) continue;
-            const long m = ((long)b * a.H + y) * a.W + x;
-            const float sp = relu20(acc[r][i] + bias);
-            if (l31 < DC_C) a.cat[m * a.ldcat + a.coff + l31] = sp;
-            if (a.spin) a.spin[m * 32 + l31] = l31 < DC_C ? sp + nx[i] : 0.f;
+        for (int j = 0; j < 4; ++j) { const _Float16 u = (_Float16)xs[j]; hi[j] = u; lo[j] = (_Float16)(xs[j] - (float)u); }
+        unsigned char* d = patch + p * PPB + (q >> 1) * 32 + (q & 1) * 8;
+        if (SLOTS % 256 == 0 || t < SLOTS) {
+            *reinterpret_cast<h4*>(d) = hi;
+            *reinterpret_cast<h4*>(d + 16) = lo;
         }
     }
+    TDX_CHAIN_BSTORE(0) TDX_CHAIN_BLOAD(3)
+    __syncthreads();
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    auto tap_mfma = [&](const unsigned char* bb, const unsigned char* ab) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            f16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                ah[m] = *reinterpret_cast<const f16x8*>(ab + m * 34 * PPB + ks * 64);
+                al[m] = *reinterpret_cast<const f16x8*>(ab + m * 34 * PPB + ks * 64 + 16);
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                bh[n] = *reinterpret_cast<const f16x8*>(bb + n * 32 * PPB + ks * 64);
+                bl[n] = *reinterpret_cast<const f16x8*>(bb + n * 32 * PPB + ks * 64 + 16);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+                }
+        }
+    };
+#define TDX_CHAIN_TAP(tap_) tap_mfma(bt + ((tap_) & 1) * C::BT + l31 * PPB + h * 32, patch + ((MT * wave + (tap_) / 3) * 34 + l31 + (tap_) % 3) * PPB + h * 32);
+    // (the LDS buffer a tap's successor is written to was last read in iteration tap - 1, before its barrier)
+    TDX_CHAIN_BSTORE(1) TDX_CHAIN_BLOAD(4) TDX_CHAIN_TAP(0) __syncthreads();
+    TDX_CHAIN_BSTORE(2) TDX_CHAIN_BLOAD(5) TDX_CHAIN_TAP(1) __syncthreads();
+    TDX_CHAIN_BSTORE(3) TDX_CHAIN_BLOAD(6) TDX_CHAIN_TAP(2) __syncthreads();
+    TDX_CHAIN_BSTORE(4) TDX_CHAIN_BLOAD(7) TDX_CHAIN_TAP(3) __syncthreads();
+    TDX_CHAIN_BSTORE(5) TDX_CHAIN_BLOAD(8) TDX_CHAIN_TAP(4) __syncthreads();
+    TDX_CHAIN_BSTORE(6) TDX_CHAIN_TAP(5) __syncthreads();
+    TDX_CHAIN_BSTORE(7) TDX_CHAIN_TAP(6) __syncthreads();
+    TDX_CHAIN_BSTORE(8) TDX_CHAIN_TAP(7) __syncthreads();
+    TDX_CHAIN_TAP(8)
+#undef TDX_CHAIN_TAP
+#undef TDX_CHAIN_BSTORE
+#undef TDX_CHAIN_BLOAD
+    // ---- epilogue (EpiChain): D col = l31 (output channel of tile n), row = (r&3) + 8*(r>>2) + 4*h (pixel of the image row)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int c = n * 32 + l31;
+        const bool real = c < CIN;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int y = y0 + MT * wave + m;
+            if (y >= a.H) continue;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int x = x0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (x >= a.W) continue;
+                const long mrow = ((long)b * a.H + y) * a.W + x;
+                const float sp = relu20(acc[m][n][i] * sc[n] + bias[n]);
+                if (real) a.cat[mrow * a.ldcat + a.coff + c] = sp;
+                if (a.spin && c < a.ldspin) a.spin[mrow * a.ldspin + c] = real ? sp + nx[n][m][i] : 0.f;
+            }
+        }
+    }
+}
+template <int CIN, int TH>
+int launch_chain_x3(const ChainX3Args& a, int B, hipStream_t st) {
+    using C = ChainX3Cfg<CIN, TH>;
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)chain_conv_x3_kernel<CIN, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    if (attr_rc != hipSuccess) return tdx::fail_hip(attr_rc, __FILE__, __LINE__);
+    hipLaunchKernelGGL((chain_conv_x3_kernel<CIN, TH>), dim3((a.W + 31) / 32, (a.H + TH - 1) / TH, B), dim3(256), C::LDS, st, a);
+    LAUNCH_CHECK();
+    return TDX_OK;
 }
 
 struct ConvW {
     size_t w, b; int N, Npad, cin, cinp, taps;
-    size_t wd = 0;       // 24 -> 24 3x3 convolutions: the weights again as [tap][k][n] (what chain_conv24_kernel stages into LDS)
     const unsigned char* hp = nullptr; const float* hs = nullptr;     // split-f16 planes [Npad][taps*cinp] + row scales (x3 core), if made
 };
 struct AffW { ConvW c0, c3; int C, inter, ipad; };
@@ -382,11 +491,6 @@ int tdx_eres2net_create(const void* blob, size_t blob_bytes, int device, tdx_ere
                 for (int t = 0; t < taps; ++t)
                     host[cw.w + ((size_t)n * taps + t) * cw.cinp + c] = (float)((double)W[((size_t)n * cin + c) * taps + t] * sc);
         }
-        if (N == 24 && cin == 24 && taps == 9) {
-            cw.wd = host.size(); host.resize(host.size() + al(9 * 24 * 24), 0.f);
-            for (int t = 0; t < 9; ++t) for (int c = 0; c < 24; ++c) for (int n = 0; n < 24; ++n)
-                host[cw.wd + ((size_t)t * 24 + c) * 24 + n] = host[cw.w + ((size_t)n * 9 + t) * cw.cinp + c];
-        }
         return cw;
     };
     auto fold_aff = [&](const std::string& p, int C) -> AffW {
@@ -454,8 +558,8 @@ int tdx_eres2net_create(const void* blob, size_t blob_bytes, int device, tdx_ere
         size_t bi = 0;
         for (int s = 0; s < NSTAGE; ++s)
             for (int i = 0; i < kBlocks[s]; ++i, ++bi) {
-                if (s < 1) continue;
                 BlockW& b = h->blocks[bi];
+                if (s < 1) { for (int j = 0; j < SCALE; ++j) jobs.push_back(&b.convs[j]); continue; }     // stage 1: the chain convolutions only
                 jobs.push_back(&b.conv1); if (b.has_sc) jobs.push_back(&b.sc);
                 for (int j = 0; j < SCALE; ++j) jobs.push_back(&b.convs[j]);
                 jobs.push_back(&b.conv3);
@@ -599,11 +703,11 @@ int tdx_eres2net_forward(tdx_eres2net* h, const float* feat, int B, int F, float
             const bool plain_next = (j + 1 < SCALE) && !b.is_aff;
             EpiChain e{h->dev + b.convs[j].b, cat, b.w4, j * b.width, b.width, b.wpad, o1, b.w4, (j + 1) * b.width,
                        plain_next ? spin[(j + 1) & 1] : nullptr};
-            if (b.width == DC_C && b.wpad == 32 && !b.is_aff) {     // stage 1: LDS-tiled direct convolution
-                DirectConvArgs da{in, ldin, h->dev + b.convs[j].wd, h->dev + b.convs[j].b, cat, b.w4, j * b.width, o1, b.w4, (j + 1) * b.width,
-                                  plain_next ? spin[(j + 1) & 1] : nullptr, Ho, Wo};
-                hipLaunchKernelGGL(chain_conv24_kernel, dim3((Wo + DC_TW - 1) / DC_TW, (Ho + DC_TH - 1) / DC_TH, B), dim3(256), 0, st, da);
-                LAUNCH_CHECK();
+            if (b.convs[j].hp && !b.is_aff && (b.width == 24 || b.width == 48)) {      // stages 1-2: LDS-tiled direct convolution (x3), fp32 input split while staged
+                ChainX3Args ca{in, ldin, b.convs[j].hp, b.convs[j].hs, 9 * b.convs[j].cinp, b.convs[j].cinp, h->dev + b.convs[j].b, cat, b.w4, j * b.width,
+                               o1, b.w4, (j + 1) * b.width, plain_next ? spin[(j + 1) & 1] : nullptr, b.wpad, Ho, Wo};
+                if (b.width == 24) TRY((launch_chain_x3<24, 4>(ca, B, st)));
+                else TRY((launch_chain_x3<48, 4>(ca, B, st)));
             } else if (x3) {     // chain input = sum of two ReLU20 outputs or an AFF blend of them (<= 40): static scale 2^9
                 if (tdx::launch_h3_split_rows_static(in, ldin, hin, M, b.wpad, 512.0f, st) != hipSuccess)
                     return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);

@@ -1120,7 +1120,8 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
             g.nseg = 2; g.M = (int)M; g.N = HQ;
             if (fuse_conv()) {      // SiLU + depthwise conv of v|u in the epilogue: planes + fp32 u straight from the GEMM (H3Conv)
                 EpiHiddenConv e{xss, M, S, 0.044194173824159216f, w.ghq, w.bhq, hid, HQ, w.cw_h, vuP, w.sv_vu, vu, Sp};
-                if (tdx::launch_gemm_h3x<false, false, false, true>(g, 1, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+                const hipError_t rc = tdx::launch_gemm_h3x<false, false, false, true>(g, 1, e, st);
+                if (rc != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
             } else {
                 EpiHiddenSN<2, true> e{xss, M, S, 0.044194173824159216f, w.ghq, w.bhq, hid, HQ};       // (SiLU in conv17)
                 if (launch_linear_x3<true>(g, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);

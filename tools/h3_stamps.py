@@ -39,11 +39,11 @@ if sys.argv[1] == "all":
         t = a[:, :5].astype(np.int64)
         ok = t[:, 4] > 0
         t = t[ok]
-        name = os.path.basename(fn)[3:-4]
+        kind, name = os.path.basename(fn)[:-4].split("_", 1)
         mang = name.split("_M")[0]
         dem = subprocess.run(["c++filt", "-t", mang], capture_output=True, text=True).stdout.strip().replace("(anonymous namespace)::", "")
         pro = (t[:, 1] - t[:, 0]).mean() / 100.0; loop = (t[:, 2] - t[:, 1]).mean() / 100.0; epi = (t[:, 4] - t[:, 2]).mean() / 100.0
-        print(f"{(dem + ' M' + name.split('_M')[1])[:60]:60s} {len(t):6d} {(t[:, 4].max() - t[:, 0].min()) / 100.0:8.1f} | {pro:8.2f} {loop:8.2f} {epi:8.2f} | {(t[:, 4] - t[:, 0]).mean() / 100.0:8.2f}")
+        print(f"{(kind + ' ' + dem + ' M' + name.split('_M')[1])[:60]:60s} {len(t):6d} {(t[:, 4].max() - t[:, 0].min()) / 100.0:8.1f} | {pro:8.2f} {loop:8.2f} {epi:8.2f} | {(t[:, 4] - t[:, 0]).mean() / 100.0:8.2f}")
         if "EpiHiddenConv" in dem:      # the fused conv epilogue: wave 0's stamps 2 (loop done) -> 3 (half 0 staged) -> 5 (half 0 convolved) -> 6 (half 1 staged) -> 4 (end)
             u = a[ok][:, [2, 3, 5, 6, 4]].astype(np.int64)
             u = u[(u[:, 1] > 0) & (u[:, 2] > 0) & (u[:, 3] > 0)]          # (v|u tiles only: the to_qk tiles do not take the conv path)

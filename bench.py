@@ -114,17 +114,17 @@ def kernel_source_sha() -> str:
 
 
 def recorded_pmc(rows: int):
-    """(traffic bytes for `rows` token rows, MFMA pipe utilisation, note) from the RECORDED PMC passes in profiles/traffic.json — not
-    measured by this run; None when the file is absent or was recorded for other kernel sources"""
+    """(traffic bytes for `rows` token rows, MFMA pipe utilisation, held clock in GHz, note) from the RECORDED PMC passes in
+    profiles/traffic.json — not measured by this run; None when the file is absent or was recorded for other kernel sources"""
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(tf):
-        return None, None, "no profiles/traffic.json"
+        return None, None, None, "no profiles/traffic.json"
     tj = json.load(open(tf))
     sha = tj.get("kernel_source_sha")
     if sha != kernel_source_sha():
-        return None, None, f"profiles/traffic.json was recorded for kernel sources {sha}, the built library is {kernel_source_sha()}: not quoted"
+        return None, None, None, f"profiles/traffic.json was recorded for kernel sources {sha}, the built library is {kernel_source_sha()}: not quoted"
     bpr = tj.get("gemm_to_hidden_hbm_bytes_per_token_row")
-    return (bpr * rows if bpr else None), tj.get("mfma_pipe_utilisation"), \
+    return (bpr * rows if bpr else None), tj.get("mfma_pipe_utilisation"), tj.get("clock_GHz_held"), \
         f"recorded PMC passes ({tj.get('source')}): HBM-side bytes = (FETCH_SIZE x2 + WRITE_SIZE) per token row x rows of this run's full launch"
 
 
@@ -362,7 +362,7 @@ def pipe_bench(args):
         gemm_flops_total = 2.0 * rows_total * 512 * 2176 * 24
         ach = gemm_flops_total / (gemm_ms * 1e-3) / 1e12 if gemm_launches else None
         full_rows = min(args.windows_per_launch, n_win_rank) * S
-        traffic, mfma_util, traffic_note = recorded_pmc(full_rows)
+        traffic, mfma_util, clock_held, traffic_note = recorded_pmc(full_rows)
         n1_ref = None
         if wl == "cfg5" and world > 1:            # the same workload on ONE GPU, measured this round (the N = 1 default line is configs[3])
             f = os.path.join(ROOT, "profiles", "r03_bench_cfg5_n1.json")
@@ -383,7 +383,9 @@ def pipe_bench(args):
                          "launches_timed": gemm_launches, "ms_per_launch": gemm_ms / max(gemm_launches, 1),
                          "algorithmic_flops_per_launch": 2.0 * full_rows * 512 * 2176,
                          "token_rows_per_full_launch": full_rows,
-                         "pmc_recorded_mfma_pipe_utilisation": mfma_util,      # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x busy cycles), recorded pass
+                         "pmc_recorded_mfma_pipe_utilisation": mfma_util,
+                         "pmc_recorded_clock_GHz": clock_held,     # the chip is power-limited under this load: the peak above assumes 2.4 GHz
+                         "frac_of_peak_at_recorded_clock": (ach / (PEAK_H3_TFLOPS * clock_held / 2.4)) if (ach and clock_held) else None,      # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x busy cycles), recorded pass
                          "traffic_source": "pmc_recorded (not measured by this run)" if traffic is not None else None,
                          "traffic_note": traffic_note,
                          "whole_path_tflops_per_gpu": sum(fl.values()) * args.steps / dt / 1e12,
@@ -501,7 +503,7 @@ def cfg2_bench(args):
         M = B * S
         gemm_flops = 2.0 * M * 512 * 2176
         ach = gemm_flops / (gemm_ms / max(gemm_launches, 1) * 1e-3) / 1e12 if gemm_launches else None
-        traffic, mfma_util, traffic_note = recorded_pmc(M)
+        traffic, mfma_util, clock_held, traffic_note = recorded_pmc(M)
         line = {
             "metric": "real-time factor (audio-sec/wall-sec), MossFormer2 separation only (sub-measurement of the full pipe), 16kHz mono",
             "value": value, "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -518,6 +520,8 @@ def cfg2_bench(args):
                          "launches_timed": gemm_launches, "ms_per_launch": gemm_ms / max(gemm_launches, 1),
                          "algorithmic_flops_per_launch": gemm_flops,
                          "pmc_recorded_mfma_pipe_utilisation": mfma_util,
+                         "pmc_recorded_clock_GHz": clock_held,     # the chip is power-limited under this load: the peak above assumes 2.4 GHz
+                         "frac_of_peak_at_recorded_clock": (ach / (PEAK_H3_TFLOPS * clock_held / 2.4)) if (ach and clock_held) else None,
                          "traffic_source": "pmc_recorded (not measured by this run)" if traffic is not None else None, "traffic_note": traffic_note,
                          "whole_path_tflops_per_gpu": flops_step * args.steps / dt / 1e12,
                          "whole_path_frac": flops_step * args.steps / dt / 1e12 / PEAK_H3_TFLOPS},

@@ -361,6 +361,162 @@ int launch_chain_x3(const ChainX3Args& a, int B, hipStream_t st) {
     return TDX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// AFF of the Res2Net chain in stages 3-4 (C = 96 / 192 channels) as ONE launch: t = silu(W0 [x | y] + b0) (C/4 channels),
+// att = 1 + tanh(W3 t + b3), out = x att + y (2 - att).  As two launches of the fp32-MFMA GEMM core the pair is bound by tile
+// latency (K = 2C: six k steps per 128-row tile, 384 us per AFF for 20 MB of operands at B = 60); here a block owns 128 rows
+// (wave w the rows 32 w ..), streams [x | y] and W0 in chunks of 32 k through double-buffered LDS tiles (next chunk in registers
+// while the MFMAs of the current one run), keeps t in LDS for the second GEMM (W3 resident) and applies the gate from x and y.
+// v_mfma_f32_32x32x2_f32 throughout: exact fp32 products like the GEMM core's.  LDS rows have a pitch of 4 mod 32 floats.
+// ---------------------------------------------------------------------------------------------------------
+struct AffArgs {
+    const float* x; long ldx; const float* y; long ldy;
+    const float* w0; int ld0; const float* b0;          // [ipad rows][2C] (pitch ld0), rows >= C/4 zero
+    const float* w3; int ld3; const float* b3;          // [C rows][ipad] (pitch ld3), columns >= C/4 zero
+    float* out; long ldo; long M;
+};
+template <int C>
+struct AffCfg {
+    static constexpr int IP = (C / 4 + 31) / 32 * 32, NT1 = IP / 32, NT2 = C / 32, NCH = 2 * C / 32;
+    static constexpr int PA = 36, PT = IP + 4;
+    static constexpr int AS = 128 * PA, WS = IP * PA;                       // floats per buffer
+    static constexpr int TS = 128 * PT;
+    static constexpr int REG1 = (2 * AS > TS ? 2 * AS : TS);                // the A ring, later t
+    static constexpr int LDS = (REG1 + 2 * WS + C * PT) * 4;
+    static constexpr int WPT = (IP * 8 + 255) / 256;                        // float4 of a W0 chunk per thread
+};
+template <int C>
+__global__ __launch_bounds__(256, C == 96 ? 2 : 1) void aff_fused_kernel(AffArgs a) {
+    using F = AffCfg<C>;
+    constexpr int IP = F::IP, NT1 = F::NT1, NT2 = F::NT2, NCH = F::NCH, PA = F::PA, PT = F::PT;
+    extern __shared__ __attribute__((aligned(16))) float ldsf[];
+    float* const As = ldsf;                              // [2][128][PA]
+    float* const Ws = ldsf + F::REG1;                    // [2][IP][PA]
+    float* const W3s = Ws + 2 * F::WS;                   // [C][PT]
+    float* const Ts = ldsf;                              // [128][PT] (after the first GEMM)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const long m0 = (long)blockIdx.x * 128;
+    // ---- chunk kc of [x | y] (128 rows x 32 k) and of W0 (IP rows x 32 k): global -> registers -> LDS buffer
+    f32x4 ra[4], rw[F::WPT];
+    auto gload = [&](int kc) {
+        const bool second = kc >= NCH / 2;
+        const float* src = second ? a.y : a.x;
+        const long ld = second ? a.ldy : a.ldx;
+        const int k0 = (second ? kc - NCH / 2 : kc) * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i, r = idx >> 3, q = idx & 7;
+            ra[i] = ldg4(src + (long)min(m0 + r, a.M - 1) * ld + k0 + 4 * q);
+        }
+#pragma unroll
+        for (int i = 0; i < F::WPT; ++i) {
+            const int idx = tid + 256 * i, n = idx >> 3, q = idx & 7;
+            if (IP * 8 % 256 == 0 || idx < IP * 8) rw[i] = ldg4(a.w0 + (long)n * a.ld0 + kc * 32 + 4 * q);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i, r = idx >> 3, q = idx & 7;
+            *reinterpret_cast<f32x4*>(As + buf * F::AS + r * PA + 4 * q) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < F::WPT; ++i) {
+            const int idx = tid + 256 * i, n = idx >> 3, q = idx & 7;
+            if (IP * 8 % 256 == 0 || idx < IP * 8) *reinterpret_cast<f32x4*>(Ws + buf * F::WS + n * PA + 4 * q) = rw[i];
+        }
+    };
+    gload(0);
+    // W3 resident: [C][IP] -> W3s[C][PT]
+    for (int idx = tid; idx < C * (IP / 4); idx += 256) {
+        const int n = idx / (IP / 4), q = idx - n * (IP / 4);
+        *reinterpret_cast<f32x4*>(W3s + n * PT + 4 * q) = ldg4(a.w3 + (long)n * a.ld3 + 4 * q);
+    }
+    lstore(0);
+    __syncthreads();
+    f32x16 acc1[NT1];
+#pragma unroll
+    for (int n = 0; n < NT1; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[n][r] = 0.f;
+#pragma unroll 1
+    for (int kc = 0; kc < NCH; ++kc) {
+        if (kc + 1 < NCH) gload(kc + 1);
+        const float* const Ab = As + (kc & 1) * F::AS + (wave * 32 + l31) * PA + 4 * h;
+        const float* const Wb = Ws + (kc & 1) * F::WS + l31 * PA + 4 * h;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(Ab + 8 * kk);
+#pragma unroll
+            for (int n = 0; n < NT1; ++n) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(Wb + n * 32 * PA + 8 * kk);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc1[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc1[n], 0, 0, 0);
+            }
+        }
+        if (kc + 1 < NCH) lstore((kc + 1) & 1);       // (that buffer was last read in iteration kc - 1, before its barrier)
+        __syncthreads();
+    }
+    // ---- t = silu(. + b0) -> Ts (the A ring is dead: every wave is past the last barrier); D col = l31, row = (r&3) + 8*(r>>2) + 4*h
+#pragma unroll
+    for (int n = 0; n < NT1; ++n) {
+        const float b0 = a.b0[n * 32 + l31];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            Ts[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * PT + n * 32 + l31] = siluf_acc(acc1[n][r] + b0);
+    }
+    // (each wave reads back only the rows it wrote: no barrier)
+    f32x16 acc2[NT2];
+#pragma unroll
+    for (int n = 0; n < NT2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[n][r] = 0.f;
+    {
+        const float* const Tb = Ts + (wave * 32 + l31) * PT + 4 * h;
+        const float* const Wb = W3s + l31 * PT + 4 * h;
+#pragma unroll
+        for (int kk = 0; kk < IP / 8; ++kk) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(Tb + 8 * kk);
+#pragma unroll
+            for (int n = 0; n < NT2; ++n) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(Wb + n * 32 * PT + 8 * kk);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc2[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc2[n], 0, 0, 0);
+            }
+        }
+    }
+    // ---- gate: att = 1 + tanh(. + b3); out = x att + y (2 - att)
+#pragma unroll
+    for (int n = 0; n < NT2; ++n) {
+        const int c = n * 32 + l31;
+        const float b3 = a.b3[c];
+        float xv[16], yv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long m = min(m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, a.M - 1);
+            xv[r] = a.x[m * a.ldx + c]; yv[r] = a.y[m * a.ldy + c];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { tdx::touch(xv[r]); tdx::touch(yv[r]); }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m >= a.M) continue;
+            const float att = 1.0f + tanhf(acc2[n][r] + b3);
+            a.out[m * a.ldo + c] = xv[r] * att + yv[r] * (2.0f - att);
+        }
+    }
+}
+template <int C>
+int launch_aff_fused(const AffArgs& a, hipStream_t st) {
+    using F = AffCfg<C>;
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)aff_fused_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, F::LDS);
+    if (attr_rc != hipSuccess) return tdx::fail_hip(attr_rc, __FILE__, __LINE__);
+    hipLaunchKernelGGL((aff_fused_kernel<C>), dim3((unsigned)((a.M + 127) / 128)), dim3(256), F::LDS, st, a);
+    LAUNCH_CHECK();
+    return TDX_OK;
+}
+
 struct ConvW {
     size_t w, b; int N, Npad, cin, cinp, taps;
     const unsigned char* hp = nullptr; const float* hs = nullptr;     // split-f16 planes [Npad][taps*cinp] + row scales (x3 core), if made
@@ -434,6 +590,10 @@ namespace {
 // AFF(x, y): GEMM1 over the two K segments [x | y], GEMM2 with the gate epilogue
 int run_aff(const tdx_eres2net* h, const AffW& a, const float* x, long ldx, const float* y, long ldy, float* tbuf, float* out, long ldo,
             long M, hipStream_t st) {
+    if (a.C == 96 || a.C == 192) {      // the chain AFFs of stages 3-4: one fused launch
+        AffArgs fa{x, ldx, y, ldy, h->dev + a.c0.w, a.c0.cinp, h->dev + a.c0.b, h->dev + a.c3.w, a.c3.cinp, h->dev + a.c3.b, out, ldo, M};
+        return a.C == 96 ? launch_aff_fused<96>(fa, st) : launch_aff_fused<192>(fa, st);
+    }
     {
         GemmSeg s0 = make_seg(x, ldx, h->dev + a.c0.w, 2L * a.C, a.C);
         GemmSeg s1 = make_seg(y, ldy, h->dev + a.c0.w + a.C, 2L * a.C, a.C);

@@ -517,6 +517,24 @@ int launch_aff_fused(const AffArgs& a, hipStream_t st) {
     return TDX_OK;
 }
 
+// static-scale split (gemm_h3.hpp h3_split_rows_static) of the pixels a stride-2 1x1 convolution reads only: planes row
+// (b, ho, wo) <- source pixel (b, 2 ho, 2 wo).  conv1 and the shortcut of a stage's first block then run as stride-1 GEMMs over
+// a quarter of the rows; splitting every pixel of the previous stage moved 4x the bytes (9.8 GB at B = 60 for stage 2).
+__global__ __launch_bounds__(256) void split_rows_static_s2_kernel(const float* __restrict__ x, int ld, unsigned char* __restrict__ planes,
+                                                                  long R, int K, int Hin, int Win, int Ho, int Wo, float s) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;       // (row, 8-value chunk)
+    const int per = K / 8;
+    if (i >= R * per) return;
+    const long row = i / per;
+    const int ch = (int)(i - row * per);
+    const long b = row / ((long)Ho * Wo);
+    const int r = (int)(row - b * Ho * Wo), ho = r / Wo, wo = r - ho * Wo;
+    const float* src = x + ((b * Hin + 2 * ho) * Win + 2 * wo) * ld + ch * 8;
+    const f32x4 a0 = ldg4(src), a1 = ldg4(src + 4);
+    const float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    h3_store_chunk(planes + row * (long)K * 4 + ch * 32, v, s);
+}
+
 struct ConvW {
     size_t w, b; int N, Npad, cin, cinp, taps;
     const unsigned char* hp = nullptr; const float* hs = nullptr;     // split-f16 planes [Npad][taps*cinp] + row scales (x3 core), if made
@@ -840,11 +858,18 @@ int tdx_eres2net_forward(tdx_eres2net* h, const float* feat, int B, int F, float
         const float* resid = x;
         if (x3) {
             // block input (ReLU20 output, <= 20) as planes with the static scale 2^10, shared by conv1 and the shortcut
-            if (tdx::launch_h3_split_rows_static(x, b.cin, hx, (long)B * Hin * Win, b.cin, 1024.0f, st) != hipSuccess)
+            int Hc = Hin, Wc = Win, sc_ = b.stride;            // geometry of the 1x1 convolutions over the planes
+            if (b.stride == 2 && b.cin % 16 == 0) {            // only the pixels the stride-2 convolutions read, compacted
+                const long R = (long)B * Ho * Wo;
+                hipLaunchKernelGGL(split_rows_static_s2_kernel, dim3((unsigned)((R * (b.cin / 8) + 255) / 256)), dim3(256), 0, st,
+                                   x, b.cin, hx, R, b.cin, Hin, Win, Ho, Wo, 1024.0f);
+                LAUNCH_CHECK();
+                Hc = Ho; Wc = Wo; sc_ = 1;
+            } else if (tdx::launch_h3_split_rows_static(x, b.cin, hx, (long)B * Hin * Win, b.cin, 1024.0f, st) != hipSuccess)
                 return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
-            TRY(conv_gemm_h3(hx, inv20, zero_row, b.conv1, B, Hin, Win, Ho, Wo, b.stride, EpiRelu20{h->dev + b.conv1.b, o1, b.w4, b.w4}, st));
+            TRY(conv_gemm_h3(hx, inv20, zero_row, b.conv1, B, Hc, Wc, Ho, Wo, sc_, EpiRelu20{h->dev + b.conv1.b, o1, b.w4, b.w4}, st));
             if (b.has_sc) {
-                TRY(conv_gemm_h3(hx, inv20, zero_row, b.sc, B, Hin, Win, Ho, Wo, b.stride, EpiBiasG{h->dev + b.sc.b, res, b.cout, b.cout}, st));
+                TRY(conv_gemm_h3(hx, inv20, zero_row, b.sc, B, Hc, Wc, Ho, Wo, sc_, EpiBiasG{h->dev + b.sc.b, res, b.cout, b.cout}, st));
                 resid = res;
             }
         } else {

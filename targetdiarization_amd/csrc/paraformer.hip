@@ -206,6 +206,12 @@ struct EpiBiasReluP { const float* b; float* out; long ld;
     __device__ float col(int, int n) const { return b[n]; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
     __device__ void store(int, int m, int n, float v, EpiNone, float c) const { out[(long)m * (int)ld + n] = fmaxf(v + c, 0.f); } };
+struct EpiBiasReluPl8 { const float* b; unsigned char* P; float* sc; long segs;   // relu(acc + b) as row-major planes, N = 2048: scale[j * segs + m] per 256-channel segment j
+    __device__ float col(int, int n) const { return b[n]; }
+    __device__ EpiNone row(int, int) const { return EpiNone{}; }
+    __device__ float val(int, int, int, float v, EpiNone, float c) const { return fmaxf(v + c, 0.f); }
+    __device__ tdx::H3PlOut plout(int) const { return tdx::H3PlOut{P, 4L * FFN, sc, nullptr, segs}; }
+    __device__ long prow(int, int m) const { return m; } };
 struct EpiBiasResP { const float* b; float* x; long ld;
     __device__ float col(int, int n) const { return b[n]; }
     __device__ EpiNone row(int, int) const { return EpiNone{}; }
@@ -416,7 +422,7 @@ size_t tdx_pfenc_workspace_bytes(const tdx_pfenc* h, int B, int T) {
     if (!h || B < 1 || T < 1) return 0;
     const size_t M = (size_t)B * T, Sp = (size_t)(T + 127) / 128 * 128;
     return (al(M * D) + al(M * DINP) + al(M * DINP) + al((M + 128) * 3 * D) + al((size_t)B * H * Sp * Sp) + al(M * D) + al(M * D) +
-            al(M * FFN) + al(M * FFN) + al(M) + PF_SLAB) * sizeof(float);      // + planes of the current GEMM's A operand (<= 2048 wide), its row scales, split-K slab
+            al(M * FFN) + al(M * FFN) + al(M) + 8 * al(M) + PF_SLAB) * sizeof(float);      // + planes of the current GEMM's A operand (<= 2048 wide), its row scales, the 8 segment scales of the FFN planes, split-K slab
 }
 
 double tdx_pfenc_flops(const tdx_pfenc* h, int B, int T) {
@@ -445,7 +451,8 @@ int tdx_pfenc_forward(tdx_pfenc* h, const float* feats, const int* lens_host, in
     unsigned char* hp = (unsigned char*)(ffn + al(M * FFN));
     float* hs = (float*)hp + al(M * FFN);
     const dim3 rows4((unsigned)((M + 3) / 4));
-    float* slab = hs + al(M);                       // split-K partial sums of the small-row path
+    float* hs8 = hs + al(M);                        // row scales of the FFN activation planes: one per (row, 256-channel segment), [8][M]
+    float* slab = hs8 + 8 * al(M);                  // split-K partial sums of the small-row path
 
     hipLaunchKernelGGL(pf_embed_kernel, dim3(T, B), dim3(256), 0, st, feats, xin, T);
     LAUNCH_CHECK();
@@ -502,11 +509,22 @@ int tdx_pfenc_forward(tdx_pfenc* h, const float* feats, const int* lens_host, in
         // ---- x += W2 relu(W1 LN(x) + b1) + b2
         hipLaunchKernelGGL(pf_layernorm_planes_kernel, rows4, dim3(256), 0, st, x, (long)D, D, w.n2g, w.n2b, hp, hs, D, M, PF_LN_EPS);
         LAUNCH_CHECK();
+        if (ns512 <= 1 && ns2048 <= 1) {
+            // relu(W1 . + b1) leaves its GEMM as row-major planes with one scale per (row, 256-channel segment) (planes-out epilogue, in the
+            // buffer of the fp32 activations they replace); W2 reads them with segmented row scales: no fp32 round trip, no split pass
+            TRY(lin3(hp, hs, w.h1, (int)M, FFN, D, EpiBiasReluPl8{w.b1, reinterpret_cast<unsigned char*>(ffn), hs8, (long)al(M)}, st));
+            H3Args g{};
+            g.seg[0] = h3_seg(ffn, hs8, 4L * FFN, w.h2.p, w.h2.s, 4L * FFN, FFN);
+            g.seg[0].segk = 256; g.seg[0].strideSeg = (long)al(M);
+            g.nseg = 1; g.M = (int)M; g.N = D;
+            if (launch_gemm_h3<false>(g, 1, EpiBiasResP{w.b2, x, D}, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+        } else {
         if (ns512 > 1) TRY(lin3_splitk<RK_BIAS_RELU>(hp, hs, w.h1, (int)M, FFN, D, ns512, slab, w.b1, ffn, FFN, nullptr, nullptr, st));
         else TRY(lin3(hp, hs, w.h1, (int)M, FFN, D, EpiBiasReluP{w.b1, ffn, FFN}, st));
         if (launch_h3_split_rows(ffn, FFN, hp, hs, M, FFN, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
         if (ns2048 > 1) TRY(lin3_splitk<RK_BIAS_RES>(hp, hs, w.h2, (int)M, D, FFN, ns2048, slab, w.b2, x, D, nullptr, nullptr, st));
         else TRY(lin3(hp, hs, w.h2, (int)M, D, FFN, EpiBiasResP{w.b2, x, D}, st));
+        }
     }
     hipLaunchKernelGGL(pf_layernorm_kernel, rows4, dim3(256), 0, st, x, (long)D, D, h->ang, h->anb, out, (long)D, D, M, PF_LN_EPS);
     LAUNCH_CHECK();

@@ -17,7 +17,8 @@ def test_encoder_vs_oracle_small_and_full():
     from oracle import paraformer_oracle as po
     from targetdiarization_amd.paraformer import ParaformerEncoder
     from targetdiarization_amd.weights import recipe_paraformer_state_dict
-    for nb, shapes in ((3, [(1, 1), (2, 37), (1, 128), (3, 129), (1, 500)]), (50, [(2, 167)])):
+    # (5, 301): > 512 rows = the large-launch path (planes-out FFN with segmented row scales, no split-K), a ragged last tile
+    for nb, shapes in ((3, [(1, 1), (2, 37), (1, 128), (3, 129), (1, 500), (5, 301)]), (50, [(2, 167)])):
         sd = recipe_paraformer_state_dict(0, nb)
         enc = ParaformerEncoder(sd, dev)
         sd64 = {k: v.double() for k, v in sd.items()}

@@ -41,6 +41,15 @@ class AudioProcessor:
         `mdx_model` (extension): the MDX net body as a callable on device tensors, spec[n,4,dim_f,256] -> spec (the
         reference runs the ONNX file through onnxruntime, AudioProcessor.py:231-233,630); without it the denoiser is off,
         like a failed `init_mdx_model` (:171-176).  `mdx_dim_f` / `mdx_n_fft`: the ONNX metadata the reference reads (:234-237)."""
+        if is_denoise_vocal and mdx_model is None and mdx_state_dict is not None:
+            # the ConvTDFNet body on the device (mdx.ConvTDFNetBody, csrc/mdx.hip) from a state dict with the PyTorch module names;
+            # `mdx_args`: its geometry (L, l, g, k, bn, dim_f, dim_t, max_blocks_per_launch).  A failure prints and leaves the denoiser
+            # off, like a failed `init_mdx_model` (AudioProcessor.py:171-176)
+            try:
+                from .mdx import ConvTDFNetBody
+                mdx_model = ConvTDFNetBody(mdx_state_dict, f"cuda:{0 if cuda_device is None else cuda_device}", **(mdx_args or {}))
+            except Exception as e:
+                print(f"Failed to init MDX model: {e}")
         self.is_denoise_vocal = bool(is_denoise_vocal and mdx_model is not None)
         self.mdx_model = mdx_model
         self.silero_vad = silero_vad            # low_gpu_ram plug-in: silero_vad(audio[n] f32 @16 kHz) -> [[start, end], ...] in samples (:903-905)

@@ -440,7 +440,9 @@ def recipe_punc_state_dict(seed: int = 0, num_blocks: int = 4, vocab: int = 4096
         if name == "embed.weight":
             t = 0.5 * u
         elif name.startswith("decoder."):
-            t = u * (2.0 if leaf == "weight" else 0.5)          # spread logits: every class gets chosen somewhere
+            t = u * (2.0 if leaf == "weight" else 0.5)          # spread logits: every class gets chosen somewhere ...
+            if leaf == "bias":
+                t = t.clone(); t[0] = -30.0                     # ... except <unk> (a trained model does not emit it; funasr would print it literally)
         elif ".norm" in name or "after_norm" in name:
             t = (1.0 + 0.2 * u) if leaf == "weight" else 0.1 * u
         elif leaf == "bias":

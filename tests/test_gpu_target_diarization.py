@@ -108,6 +108,39 @@ def test_infer_with_device_decoder_and_denoiser(gold, sd2):
     assert any(t for t in texts) and all(t == "" or t.startswith(" w") for t in texts)
 
 
+def test_infer_with_the_device_mdx_body_and_punctuation(gold, sd2):
+    """every neural stage of infer() on the device: audio_preprocess with the ConvTDFNet denoiser body (N3, `mdx_state_dict`; small geometry),
+    separation, embeddings, Paraformer encoder + CIF + NAR decoder (N2) and the CT-Transformer punctuation restorer (N3, `punc_state_dict`):
+    the result texts are the decoder's tokens with punctuation marks from the device model's own inference() on the same text"""
+    from targetdiarization_amd.target_diarization import TargetDiarization
+    from targetdiarization_amd.weights import (recipe_eres2netv2_state_dict, recipe_mdx_state_dict, recipe_paraformer_decoder_state_dict,
+                                               recipe_paraformer_state_dict, recipe_punc_state_dict)
+    mix, tgt = _load(gold, "chat_mix.wav"), _load(gold, "female_a.wav")
+    asr_sd = dict(recipe_paraformer_state_dict(0, 2)); asr_sd.update(recipe_paraformer_decoder_state_dict(0, 2))
+    sd_rows = {"text": [[0.0, 3.0, 0], [2.4, 5.5, 1], [5.5, 8.6, 0]]}
+    od = [(0.0, 3.0, "SPEAKER_00"), (2.4, 5.5, "SPEAKER_01"), (5.5, 8.6, "SPEAKER_00")]
+    geo = dict(L=3, l=1, g=32, bn=8, dim_f=3072)
+    chars = [chr(0x4e00 + i) for i in range(8404)]                      # one CJK ideograph per token id
+    td = TargetDiarization(cuda_device=0, sep_state_dict=sd2, spk_state_dict=recipe_eres2netv2_state_dict(0), asr_state_dict=asr_sd,
+                           sd_pipeline=lambda a: sd_rows, od_pipeline=lambda a: od, token_list=chars,
+                           mdx_state_dict=recipe_mdx_state_dict(2, **geo), mdx_args=dict(geo, dim_t=256, max_blocks_per_launch=2),
+                           mdx_weights_file="mdx/weights/UVR-MDX-NET-Inst_HQ_3.onnx", punc_state_dict=recipe_punc_state_dict(0, vocab=512))
+    assert td.hp.ap.is_denoise_vocal and td.hp.dec is not None and td.punctuation is not None
+    pre = td.audio_preprocess(mix)
+    assert pre.shape == mix.shape and np.isfinite(pre).all()
+    assert np.abs(pre - mix).max() > 1e-4                               # the denoiser body ran (recipe weights: it changes the audio)
+    spk, res, aud = td.infer(mix, tgt)
+    assert spk in ("0", "1") and res and aud is not None and np.isfinite(aud).all()
+    marks = set("，。？、")
+    texts = [r["text"] for r in res if r["text"]]
+    assert texts
+    for t in texts:
+        bare = "".join(ch for ch in t if ch not in marks)
+        assert bare and all(0x4e00 <= ord(ch) < 0x4e00 + 8404 for ch in bare)
+        assert t[-1] in "。？"                                           # CTTransformer.inference ends a text with a sentence end
+        assert t == td.punctuation(bare)
+
+
 def test_serving_shell_over_the_device_model(gold, sd2):
     """N4: POST /diarization/infer with the config-1 assets as multipart uploads gives the same decisions as a direct infer()"""
     pytest.importorskip("fastapi")

@@ -84,3 +84,8 @@ def test_punctuation_plugs_into_asr_processor():
     t = asrp.punctuation_restore("大家好 我们 开始 吧")
     assert isinstance(t, str) and t.replace("，", "").replace("。", "").replace("？", "").replace("、", "").replace(" ", "") == "大家好我们开始吧"
     assert m(["你好", ""]) [1] == ""
+    # the constructor path of the reference (`is_punc` + a model directory there; a state dict here): same texts, lists handled like :893-896
+    asrp2 = ASRProcessor(punc_state_dict=recipe_punc_state_dict(0, vocab=512))
+    assert asrp2.is_punc and asrp2.punctuation_restore("大家好 我们 开始 吧") == t
+    assert asrp2.punctuation_restore(["大家好 我们 开始 吧", ""]) == [t, ""]
+    assert ASRProcessor().punctuation_restore("abc") == "abc" and not ASRProcessor().is_punc

@@ -233,6 +233,15 @@ def pipe_bench(args):
     hp = HotPath(sep_sd, spk_sd, asr_sd, cuda_device=local_rank, windows_per_launch=args.windows_per_launch,
                  asr_rows_per_launch=args.asr_rows_per_launch)
     hp.spk.max_batch_frames = args.embed_frames_per_launch
+    punc = token_list = None
+    if with_asr and wl == "cfg4" and not args.no_punc:
+        # configs[3] names the CT-Transformer punctuation stage: the device model (punctuation.CTTransformer, funasr's geometry and its
+        # 272 727-word embedding table, recipe weights) restores the punctuation of every recognised 30 s segment inside the timed step;
+        # token id k of the recogniser reads as the CJK ideograph U+4E00 + k, word w has the punctuation-vocabulary id 1 + (ord(w) - 0x4E00)
+        from targetdiarization_amd.punctuation import CTTransformer
+        from targetdiarization_amd.weights import recipe_punc_state_dict
+        punc = CTTransformer(recipe_punc_state_dict(0, num_blocks=4, vocab=272727), device=f"cuda:{local_rank}", vocab=lambda w: 1 + (ord(w[0]) - 0x4E00) % 272726)
+        token_list = [chr(0x4E00 + i) for i in range(8404)]
     target = torch.from_numpy(np.random.default_rng(5).standard_normal(192).astype(np.float32)).to(dev)
 
     if wl in ("cfg3", "cfg4"):
@@ -246,7 +255,8 @@ def pipe_bench(args):
         windows_local = nwin
         desc = (f"BASELINE {'configs[2]' if wl == 'cfg3' else 'configs[3]'}: {total_s} s synthetic conversation (two alternating speakers, 20 % overlap) = {nwin} x 10 s windows: "
                 f"MossFormer2 ({args.windows_per_launch} windows per launch) -> loudness swap -> ERes2NetV2 on every 10 s window of both streams "
-                "+ cosine vs a target embedding" + (" -> Paraformer (SANM encoder, CIF predictor, NAR decoder, argmax tokens + timestamps) on 30 s segments of both streams, punctuation pass-through" if with_asr else "")
+                "+ cosine vs a target embedding" + (" -> Paraformer (SANM encoder, CIF predictor, NAR decoder, argmax tokens + timestamps) on 30 s segments of both streams -> "
+                   + ("CT-Transformer punctuation of every segment's text on the device (all segments in lock step)" if punc is not None else "punctuation pass-through") if with_asr else "")
                 + "; recipe weights; input resident in HBM, results (separated streams, embeddings, scores, tokens) copied to the host inside the timed region")
         sample_window = rec_np[:WINDOW]
     else:   # cfg5
@@ -272,7 +282,7 @@ def pipe_bench(args):
         utts = inputs if inputs is not None else batches[k % len(batches)]
         # to_host="results": the D2H of the results is INSIDE the timed region ("... to end of D2H")
         return hp.run(utts, target, rank, world, n_step_total, with_asr=with_asr, to_host="results", embed_segment=embed_segment,
-                      cluster=(wl == "cfg5" and rank == 0))
+                      cluster=(wl == "cfg5" and rank == 0), punctuation=punc, token_list=token_list)
 
     def barrier():
         if use_dist:
@@ -333,12 +343,20 @@ def pipe_bench(args):
         from targetdiarization_amd import ops
         ops.cosine_scores(hp.spk.embed_device(clips), target)
         ev[2].record()
+        dres = None
         if with_asr:
-            hp.encode_device(flat, decode=True)
+            _, dres = hp.encode_device(flat, decode=True)
         ev[3].record()
         torch.cuda.synchronize(dev)
         stage_ms = {"separation+loudness": ev[0].elapsed_time(ev[1]), "embedding+cosine": ev[1].elapsed_time(ev[2]),
                     "asr_encoder+decoder": ev[2].elapsed_time(ev[3]) if with_asr else 0.0}
+        if punc is not None and dres is not None:             # host wall time: device forwards + the host's window / cache / text logic
+            texts = ["".join(token_list[i] for i in seg["token_ids"]) for stream in dres for seg in stream]
+            tp = time.perf_counter()
+            pres = punc.inference_batch(texts)
+            stage_ms["punctuation (wall)"] = (time.perf_counter() - tp) * 1e3
+            stage_ms["punctuation_texts"] = len(texts)
+            stage_ms["punctuation_words"] = sum(len(r[1]) for r in pres)
     if use_dist:
         dist.barrier()
 
@@ -644,6 +662,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="cfg2: windows per GPU")
     ap.add_argument("--seconds", type=float, default=4.0, help="cfg2: window length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-punc", action="store_true", help="configs[3] without the CT-Transformer punctuation stage (the round-1/2 form of the workload: pass-through)")
     ap.add_argument("--dry-run", action="store_true", help="rank plumbing on the CPU (gloo), no kernels")
     args = ap.parse_args()
     if args.gpus < 1:

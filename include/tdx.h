@@ -186,14 +186,18 @@ int tdx_mdx_forward(tdx_mdx* h, const float* spec_dev, int B, float* out_dev, vo
  *     ASRProcessor.punctuation_restore  ASRProcessor.py:880-897  (funasr CTTransformer.punc_forward: third-party):
  *     Embedding(vocab, 256) -> SANM encoder (num_blocks layers, d 256, 8 heads, FFN 1024, FSMN k = 11) -> Linear(256, npunc).
  *     blob: TDXW container with funasr's names (embed.weight, encoder.encoders0.0.*, encoder.encoders.{i}.*, encoder.after_norm.*,
- *     decoder.*).  ids_dev int32 [B,T] (equal-length token id rows, T <= 1024) -> logits_dev [B,T,npunc].  The mini-sentence
- *     windows, the sentence cache and the text assembly are host logic (targetdiarization_amd/punctuation.py).
+ *     decoder.*).  ids_dev int32 [B,T] (T <= 1024) -> logits_dev [B,T,npunc].  lens_dev: null (every row has T tokens) or int32 [B]:
+ *     row b holds lens[b] <= T tokens, the rest is padding — masked in the attention and zero in the FSMN memory, like funasr's
+ *     padding mask, so that the valid positions equal the unbatched result (rows of many texts in one launch sequence); logits of
+ *     padding positions are unspecified.  The mini-sentence windows, the sentence cache and the text assembly are host logic
+ *     (targetdiarization_amd/punctuation.py).
  * ---------------------------------------------------------------------------------- */
 typedef struct tdx_punc tdx_punc;
 int tdx_punc_create(int num_blocks, int vocab, int npunc, const void* weights_blob, size_t blob_bytes, int device, tdx_punc** out);
 int tdx_punc_destroy(tdx_punc* h);
 size_t tdx_punc_workspace_bytes(const tdx_punc* h, int B, int T);
-int tdx_punc_forward(tdx_punc* h, const int* ids_dev, int B, int T, float* logits_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+int tdx_punc_forward(tdx_punc* h, const int* ids_dev, const int* lens_dev, int B, int T, float* logits_dev, void* workspace_dev, size_t workspace_bytes,
+                     void* stream);
 
 /* ------------------------------------------------------------------------------------
  * a12 Paraformer-large SANM encoder — replaces the encoder forward inside

@@ -64,7 +64,7 @@ SIGNATURES = {
     "tdx_punc_create": (_i, [_i, _i, _i, _vp, _sz, _i, C.POINTER(_vp)]),
     "tdx_punc_destroy": (_i, [_vp]),
     "tdx_punc_workspace_bytes": (_sz, [_vp, _i, _i]),
-    "tdx_punc_forward": (_i, [_vp, _vp, _i, _i, _fp, _vp, _sz, _vp]),
+    "tdx_punc_forward": (_i, [_vp, _vp, _vp, _i, _i, _fp, _vp, _sz, _vp]),
     "tdx_pfenc_create": (_i, [_i, _vp, _sz, _i, C.POINTER(_vp)]),
     "tdx_pfenc_destroy": (_i, [_vp]),
     "tdx_pfenc_workspace_bytes": (_sz, [_vp, _i, _i]),

@@ -57,27 +57,30 @@ __global__ __launch_bounds__(256) void punc_ln_kernel(const float* __restrict__ 
     *reinterpret_cast<float4*>(y + row * PD + 4 * lane) = make_float4(a0 * r * gg.x + bb.x, a1 * r * gg.y + bb.y, a2 * r * gg.z + bb.z, a3 * r * gg.w + bb.w);
 }
 // FSMN memory: mem[b,t,c] = v[b,t,c] + sum_j w[c][j] v[b,t + j - 5,c]   (depthwise over time, zero padded; v = qkv[:, 512:768])
-__global__ __launch_bounds__(256) void punc_fsmn_kernel(const float* __restrict__ qkv, const float* __restrict__ wT /* [11][256] */, float* __restrict__ mem, int T) {
+__global__ __launch_bounds__(256) void punc_fsmn_kernel(const float* __restrict__ qkv, const float* __restrict__ wT /* [11][256] */, float* __restrict__ mem, int T,
+                                                       const int* __restrict__ lens) {
     const int row = blockIdx.x, c = threadIdx.x;
     const int t = row % T;
+    const int L = lens ? min(lens[row / T], T) : T;          // rows >= L of a batch entry are padding: they read as zero (funasr: inputs * mask)
     const long base = (long)(row - t) * (3 * PD) + 2 * PD + c;
-    float acc = qkv[base + (long)t * (3 * PD)];
+    float acc = t < L ? qkv[base + (long)t * (3 * PD)] : 0.f;
 #pragma unroll
     for (int j = 0; j < PKS; ++j) {
         const int tt = t + j - (PKS - 1) / 2;
-        if (tt >= 0 && tt < T) acc = fmaf(wT[j * PD + c], qkv[base + (long)tt * (3 * PD)], acc);
+        if (tt >= 0 && tt < L) acc = fmaf(wT[j * PD + c], qkv[base + (long)tt * (3 * PD)], acc);
     }
     mem[(long)row * PD + c] = acc;
 }
 // softmax(q k^T / sqrt(32)) v for 8 query rows of one (batch, head); T <= PMAXT
-__global__ __launch_bounds__(256) void punc_attn_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int T) {
+__global__ __launch_bounds__(256) void punc_attn_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int T, const int* __restrict__ lens) {
     __shared__ float qs[8][PDK];
     __shared__ float p[8][PMAXT];
     const int b = blockIdx.z, h = blockIdx.y, r0 = blockIdx.x * 8, tid = threadIdx.x;
     const float* base = qkv + (long)b * T * (3 * PD);
+    const int L = lens ? min(lens[b], T) : T;                // keys >= L are padding (masked); L = 0: the context rows are written as zeros
     { const int r = tid >> 5, d = tid & 31; qs[r][d] = base[(long)min(r0 + r, T - 1) * (3 * PD) + h * PDK + d] * 0.17677669529663687f; }
     __syncthreads();
-    for (int j = tid; j < T; j += 256) {
+    for (int j = tid; j < L; j += 256) {
         const float* kp = base + (long)j * (3 * PD) + PD + h * PDK;
         float acc[8];
 #pragma unroll
@@ -98,14 +101,14 @@ __global__ __launch_bounds__(256) void punc_attn_kernel(const float* __restrict_
         for (int rr = 0; rr < 2; ++rr) {
             float* row = p[2 * w + rr];
             float mx = -INFINITY;
-            for (int c = lane; c < T; c += 64) mx = fmaxf(mx, row[c]);
+            for (int c = lane; c < L; c += 64) mx = fmaxf(mx, row[c]);
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
             float sum = 0.f;
-            for (int c = lane; c < T; c += 64) { const float e = expf(row[c] - mx); row[c] = e; sum += e; }
+            for (int c = lane; c < L; c += 64) { const float e = expf(row[c] - mx); row[c] = e; sum += e; }
             sum = wave_sum(sum);
-            const float inv = 1.0f / sum;
-            for (int c = lane; c < T; c += 64) row[c] *= inv;
+            const float inv = L > 0 ? 1.0f / sum : 0.f;
+            for (int c = lane; c < L; c += 64) row[c] *= inv;
         }
     }
     __syncthreads();
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256) void punc_attn_kernel(const float* __restrict_
         const int r = tid >> 5, d = tid & 31;
         const float* vp = base + 2 * PD + h * PDK + d;
         float acc = 0.f;
-        for (int j = 0; j < T; ++j) acc = fmaf(p[r][j], vp[(long)j * (3 * PD)], acc);
+        for (int j = 0; j < L; ++j) acc = fmaf(p[r][j], vp[(long)j * (3 * PD)], acc);
         if (r0 + r < T) ctx[((long)b * T + r0 + r) * PD + h * PDK + d] = acc;
     }
 }
@@ -220,7 +223,7 @@ size_t tdx_punc_workspace_bytes(const tdx_punc* h, int B, int T) {
     return (al(M * PD) * 4 + al(M * 3 * PD) + al(M * PFFN) + 1024) * sizeof(float);
 }
 
-int tdx_punc_forward(tdx_punc* h, const int* ids, int B, int T, float* logits, void* ws_, size_t ws_bytes, void* stream) {
+int tdx_punc_forward(tdx_punc* h, const int* ids, const int* lens, int B, int T, float* logits, void* ws_, size_t ws_bytes, void* stream) {
     if (!h || !ids || !logits || !ws_) return tdx::fail(TDX_E_INVALID, "tdx_punc_forward: null argument");
     if (B < 1 || T < 1 || T > PMAXT) return tdx::fail(TDX_E_INVALID, "tdx_punc_forward: need 1 <= T <= 1024");
     if (ws_bytes < tdx_punc_workspace_bytes(h, B, T)) return tdx::fail(TDX_E_WORKSPACE, "tdx_punc_forward: workspace too small");
@@ -238,9 +241,9 @@ int tdx_punc_forward(tdx_punc* h, const int* ids, int B, int T, float* logits, v
         hipLaunchKernelGGL(punc_ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, d + w.n1g, d + w.n1b, hn, M, 1e-12f);
         LAUNCH_CHECK();
         TRY(lin(hn, PD, d + w.Wqkv, (int)M, 3 * PD, PD, EpiB{d + w.bqkv, qkv, 3 * PD, 3 * PD}, st));
-        hipLaunchKernelGGL(punc_fsmn_kernel, dim3((unsigned)M), dim3(256), 0, st, qkv, d + w.fsmnT, mem, T);
+        hipLaunchKernelGGL(punc_fsmn_kernel, dim3((unsigned)M), dim3(256), 0, st, qkv, d + w.fsmnT, mem, T, lens);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(punc_attn_kernel, dim3((T + 7) / 8, PH, B), dim3(256), 0, st, qkv, ctx, T);
+        hipLaunchKernelGGL(punc_attn_kernel, dim3((T + 7) / 8, PH, B), dim3(256), 0, st, qkv, ctx, T, lens);
         LAUNCH_CHECK();
         TRY(lin(ctx, PD, d + w.Wo, (int)M, PD, PD, EpiBRes{d + w.bo, mem, x}, st));                 // x += att W_o + b_o + mem
         hipLaunchKernelGGL(punc_ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, d + w.n2g, d + w.n2b, hn, M, 1e-12f);

@@ -179,7 +179,8 @@ class HotPath:
 
     # ---- whole path over a shard ------------------------------------------------------------
     def run(self, utts, target_embedding=None, rank: int = 0, world: int = 1, n_total: int | None = None, with_asr: bool = True,
-            to_host: bool = True, embed_segment: int | None = None, target_clip=None, cluster: bool = False):
+            to_host: bool = True, embed_segment: int | None = None, target_clip=None, cluster: bool = False,
+            punctuation=None, token_list=None):
         """utts: THIS rank's utterances (utterance i of the job lives on rank i % world), host arrays or
         device tensors.  Returns dict with the separated streams, the all-gathered embeddings [n_total*k,192]
         (utterance order), cosine scores vs `target_embedding`, and encoder outputs of the local streams.
@@ -281,4 +282,14 @@ class HotPath:
             if enc_h is not None:
                 out["encoder"] = [h.numpy() for h in enc_h]
             out["d2h_bytes"] = sum(h.numel() * h.element_size() for h in keep)
+        if punctuation is not None and "asr" in out:
+            # CT-Transformer punctuation of every recognised segment (ASRProcessor.punctuation_restore per chunk text, TargetDiarization.py:816):
+            # all segments of all streams in lock step through the device model (punctuation.CTTransformer.inference_batch)
+            tl = token_list
+            texts = ["".join((tl[i] if tl is not None and i < len(tl) else f" <{i}>") for i in seg["token_ids"]) for stream in out["asr"] for seg in stream]
+            res = punctuation.inference_batch(texts) if hasattr(punctuation, "inference_batch") else [(punctuation(t), None) for t in texts]
+            k = 0
+            for stream in out["asr"]:
+                for seg in stream:
+                    seg["text"] = res[k][0]; k += 1
         return out

@@ -20,6 +20,7 @@ class _HostOnly:
         from targetdiarization_amd.punctuation import CTTransformer
         self.__class__ = type("H", (CTTransformer,), {"__init__": lambda s: None, "__del__": lambda s: None})
         self.punc_list, self.sentence_end_id, self.unk_id, self.vocab, self.vocab_size = list(PUNC_LIST), 3, 0, None, 1000
+        self._marks = ["" if p == "_" else p for p in self.punc_list]
 
 
 def test_inference_cache_and_assembly():
@@ -49,6 +50,55 @@ def test_inference_cache_and_assembly():
     out2, _ = h.inference("hello world how are you", forward=fwd2)
     assert out2 == "Hello world. How are you."
     assert h.inference("", forward=fwd2) == ("", [])
+
+
+def test_inference_batch_in_lock_step_equals_text_by_text():
+    h = _HostOnly()
+
+    def logits_of(ids):           # a deterministic function of the token AND its position in the window (like a real model: context matters)
+        ids = np.asarray(ids)
+        lg = np.zeros((len(ids), 6), np.float32); lg[:, 1] = 1.0
+        for i, t in enumerate(ids):
+            k = (int(t) * 7 + i * 3) % 11
+            if k == 0: lg[i, 3] = 2.0
+            elif k == 1: lg[i, 2] = 2.0
+            elif k == 2: lg[i, 4] = 2.0
+        return lg
+
+    def fwd_b(ids, lens):         # padded batch: garbage in the padding must not matter
+        out = np.full((ids.shape[0], ids.shape[1], 6), 9.0, np.float32)
+        for r in range(ids.shape[0]):
+            out[r, :lens[r]] = logits_of(ids[r, :lens[r]])
+        return out
+    texts = ["字" * 50, "", "hello world how are you doing today my friend", "一二三四五六七八九十" * 9 + " ok fine", "短"]
+    one = [h.inference(t, forward=logits_of) for t in texts]
+    calls = []
+    many = h.inference_batch(texts, forward=lambda ids, lens: (calls.append(ids.shape), fwd_b(ids, lens))[1])
+    assert many == one
+    assert len(calls) == 5 and calls[0][0] == 4 and calls[-1][0] == 1          # 92 words = 5 windows; four non-empty texts start together
+
+
+@pytest.mark.gpu
+def test_padded_batch_with_lens_equals_single_rows():
+    """rows of different lengths in one launch sequence (lens_dev: attention mask + zero FSMN memory beyond the row's length) give the
+    logits of the rows run alone; inference_batch() gives the texts of inference()"""
+    from targetdiarization_amd.punctuation import CTTransformer
+    from targetdiarization_amd.weights import recipe_punc_state_dict
+    m = CTTransformer(recipe_punc_state_dict(0, num_blocks=4, vocab=4096), "cuda:0")
+    rng = np.random.default_rng(1)
+    lens = np.array([37, 1, 20, 0, 226, 5], dtype=np.int32)
+    ids = rng.integers(0, 4096, (len(lens), int(lens.max())))
+    out = m.punc_forward(ids, lens)
+    for r, n in enumerate(lens):
+        if n == 0:
+            continue
+        ref = m.punc_forward(ids[r, :n])
+        assert np.abs(out[r, :n] - ref).max() <= 2e-5 * np.abs(ref).max(), (r, n)
+    texts = ["今天天气怎么样我们去公园散步好不好 then we can have lunch together 之后再回家休息一下明天还要上班" * 3, "", "你好", "hello world " * 30]
+    assert m.inference_batch(texts) == [m.inference(t) for t in texts]
+    assert m(texts) == [m.inference(t)[0] for t in texts]
+    with pytest.raises(Exception):
+        m.punc_forward(ids, lens + 300)
 
 
 @pytest.mark.gpu

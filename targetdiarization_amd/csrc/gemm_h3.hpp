@@ -107,6 +107,7 @@ struct H3Args {
     int M, N;                    // valid rows / columns (PAIRED: N = number of pair columns, multiple of 128)
     int tiles_m, tiles_n;
     int map_mode, mp, gw, batches;
+    int mc;                      // map_mode 0: M tiles per chunk of an XCD's range (0 = the whole range), see the block -> tile map
     int pair_off;
     // A_CONV (implicit GEMM over NHWC pixel rows): output row m = (b, h, w) of [B, Hout, Wout]; K segment `tap` (cv_cin
     // values) reads the planes row of input pixel (b, h*stride+dy, w*stride+dx), (dy,dx) = (tap/3-1, tap%3-1) for 9
@@ -444,12 +445,16 @@ __global__ __launch_bounds__(H3_THREADS, 2) void gemm_h3_kernel(H3Args g, Epi ep
         const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
         if (g.map_mode == 0) {
             z = blockIdx.y;
-            const int per = g.mp * g.gw, ngf = g.tiles_n / g.gw;
-            const int p = i / per;
+            // the XCD's M range in chunks of g.mc M tiles (0: one chunk): all N groups sweep a chunk before the next chunk starts, so
+            // that the A rows a later group re-reads are still in the Infinity Cache (one sweep of the whole range evicts them)
+            int i2 = i, mbase = 0, mcur = g.mp;
+            if (g.mc > 0) { const int tpc = g.mc * g.tiles_n, c = i / tpc; i2 = i - c * tpc; mbase = c * g.mc; mcur = min(g.mc, g.mp - mbase); }
+            const int per = mcur * g.gw, ngf = g.tiles_n / g.gw;
+            const int p = i2 / per;
             int lm, n;
-            if (p < ngf) { const int j = i - p * per; lm = j / g.gw; n = p * g.gw + (j - lm * g.gw); }
-            else { const int rem = g.tiles_n - ngf * g.gw; const int j = i - ngf * per; lm = j / rem; n = ngf * g.gw + (j - lm * rem); }
-            bm = x * g.mp + lm; bn = n;
+            if (p < ngf) { const int j = i2 - p * per; lm = j / g.gw; n = p * g.gw + (j - lm * g.gw); }
+            else { const int rem = g.tiles_n - ngf * g.gw; const int j = i2 - ngf * per; lm = j / rem; n = ngf * g.gw + (j - lm * rem); }
+            bm = x * g.mp + mbase + lm; bn = n;
             if (bm >= g.tiles_m) return;
         } else {
             const int tpb = g.tiles_m * g.tiles_n;
@@ -1346,6 +1351,13 @@ inline hipError_t launch_gemm_h3x(H3Args g, int batches, Epi epi, hipStream_t st
         if (gw < 1) gw = 1;
         if (gw > g.tiles_n) gw = g.tiles_n;
         g.gw = (int)gw;
+        // several N groups re-read the A rows: keep a chunk's rows (per XCD <= ~6 MB, 48 MB on the chip) inside the 256 MB Infinity Cache
+        static const int mc_env = [] { const char* e = getenv("TDX_H3_MC"); return e ? atoi(e) : -1; }();
+        g.mc = 0;
+        if (g.gw < g.tiles_n) {
+            long mc = mc_env >= 0 ? mc_env : (6L * 1024 * 1024) / (256L * ktot * 4);
+            if (mc > 0 && mc < g.mp) g.mc = (int)mc;
+        }
         grid = dim3(8 * g.mp * g.tiles_n, batches, 1);
     } else {
         g.map_mode = 1;

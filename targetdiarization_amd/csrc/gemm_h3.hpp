@@ -1347,7 +1347,8 @@ inline hipError_t launch_gemm_h3x(H3Args g, int batches, Epi epi, hipStream_t st
         g.mp = (g.tiles_m + 7) / 8;
         long ktot = 0;
         for (int i = 0; i < g.nseg; ++i) ktot += g.seg[i].K;
-        long gw = (1536L * 1024) / (256L * ktot * 4);      // weight slice of a group stays in the XCD's L2
+        static const long gw_kb = [] { const char* e = getenv("TDX_H3_GW_KB"); return e ? atol(e) : 1536L; }();
+        long gw = (gw_kb * 1024) / (256L * ktot * 4);      // weight slice of a group stays in the XCD's L2
         if (gw < 1) gw = 1;
         if (gw > g.tiles_n) gw = g.tiles_n;
         g.gw = (int)gw;

@@ -655,7 +655,7 @@ def main():
                     help="default: cfg4 (BASELINE configs[3], the full pipe on 1800 s) at one GPU, cfg5 (BASELINE configs[4], the "
                          "1000-utterance job, strong scaling) at more; cfg2 = MossFormer2 only; cfg3 = 600 s without the ASR encoder")
     ap.add_argument("--asr-rows-per-launch", type=int, default=65536, help="LFR frames per Paraformer launch sequence")
-    ap.add_argument("--embed-frames-per-launch", type=int, default=160000, help="fbank frames per ERes2NetV2 launch sequence")
+    ap.add_argument("--embed-frames-per-launch", type=int, default=180000, help="fbank frames per ERes2NetV2 launch sequence (180 x 10 s windows: the 360 clips of the default workload in two equal launch sequences; measured 120k / 180k / 360k: 550.8 / 538.7 / 532.0 ms per step at 154 / 179 / 255 GiB peak)")
     ap.add_argument("--windows-per-launch", type=int, default=90, help="10 s windows per MossFormer2 launch sequence (90 = 1.8 M token rows: the launches get larger, not more — DESIGN.md §5)")
     ap.add_argument("--utterances", type=int, default=1000, help="cfg5: utterances in the job")
     ap.add_argument("--utterances-per-step", type=int, default=200, help="cfg5: utterances per step (global batch, all ranks together)")

@@ -626,6 +626,32 @@ int run_aff(const tdx_eres2net* h, const AffW& a, const float* x, long ldx, cons
     return TDX_OK;
 }
 
+// fuse34 (C = 2048, M >= 8192 rows) on the x3 core: GEMM1 as TWO K segments — x (a ReLU20 output) as planes with the static scale 2^10,
+// y (layer3_ds: no activation) as planes with exact row scales — then t as planes with row scales for GEMM2 + the gate epilogue.
+// Against the fp32-MFMA core (K = 4096: 105 TFLOP/s): 3.0 + 1.5 ms -> ~2.2 ms incl. the three split passes at B = 60.
+int run_aff34_x3(const tdx_eres2net* h, const AffW& a, const float* x, const float* y, float* tbuf, float* out, long M,
+                 unsigned char* xP, unsigned char* yP, float* ys, unsigned char* tP, float* ts, const float* inv20, hipStream_t st) {
+    const int C = a.C, IP = a.ipad;
+    if (tdx::launch_h3_split_rows_static(x, C, xP, M, C, 1024.0f, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    if (tdx::launch_h3_split_rows(y, C, yP, ys, M, C, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    {
+        H3Args g{};
+        g.seg[0] = h3_seg(xP, inv20, 4L * C, a.c0.hp, a.c0.hs, 4L * 2 * C, C);
+        g.seg[0].sa_mul = 0;
+        g.seg[1] = h3_seg(yP, ys, 4L * C, a.c0.hp + 4L * C, a.c0.hs, 4L * 2 * C, C);
+        g.nseg = 2; g.M = (int)M; g.N = a.c0.Npad;
+        if (launch_gemm_h3x<false, false, false, true>(g, 1, EpiAffSilu{h->dev + a.c0.b, tbuf, IP}, st) != hipSuccess)
+            return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    }
+    if (tdx::launch_h3_split_rows(tbuf, IP, tP, ts, M, IP, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    H3Args g{};
+    g.seg[0] = h3_seg(tP, ts, 4L * IP, a.c3.hp, a.c3.hs, 4L * IP, IP);
+    g.nseg = 1; g.M = (int)M; g.N = a.c3.Npad;
+    if (launch_gemm_h3<false>(g, 1, EpiAffGate{h->dev + a.c3.b, x, (long)C, y, (long)C, out, (long)C, C}, st) != hipSuccess)
+        return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
+    return TDX_OK;
+}
+
 struct Dims { int H[5], W[5]; };
 inline Dims make_dims(int F) {
     Dims d; d.H[0] = 80; d.W[0] = F;
@@ -743,6 +769,7 @@ int tdx_eres2net_create(const void* blob, size_t blob_bytes, int device, tdx_ere
                 jobs.push_back(&b.conv3);
             }
         jobs.push_back(&h->ds);
+        jobs.push_back(&h->fuse34.c0); jobs.push_back(&h->fuse34.c3);
         size_t bytes = 0;
         for (ConvW* c : jobs) bytes += (size_t)c->Npad * c->taps * c->cinp * 4 + al(c->Npad) * 4;
         e = hipMalloc(&h->dev_planes, bytes);
@@ -925,7 +952,12 @@ int tdx_eres2net_forward(tdx_eres2net* h, const float* feat, int B, int F, float
         TRY(conv_gemm_h3_tapsplit(hx, inv20, zero_row, h->ds, B, d.H[3], d.W[3], d.H[4], d.W[4], 2, slab, nullptr, P[i_ds], st));
     else
         TRY(conv_gemm_h3(hx, inv20, zero_row, h->ds, B, d.H[3], d.W[3], d.H[4], d.W[4], 2, EpiBiasG{nullptr, P[i_ds], 2048, 2048}, st));
-    TRY(run_aff(h, h->fuse34, x, 2048, P[i_ds], 2048, tbuf, P[i_fu], 2048, M4, st));
+    const char* aff34_env = getenv("TDX_ERES_AFF34_ROWS");             // (tests force the x3 path at small sizes)
+    const long aff34_min = aff34_env ? atol(aff34_env) : 8192;
+    if (M4 >= aff34_min && 2 * M4 <= (long)B * 40960 && h->fuse34.c0.hp && h->fuse34.ipad == 512)      // (fewer rows: a handful of 256-row tiles with 256 k steps each — the fp32 core's smaller tiles win)
+        TRY(run_aff34_x3(h, h->fuse34, x, P[i_ds], tbuf, P[i_fu], M4, hx, hcat, stats, hin, stats + M4, inv20, st));
+    else
+        TRY(run_aff(h, h->fuse34, x, 2048, P[i_ds], 2048, tbuf, P[i_fu], 2048, M4, st));
     hipLaunchKernelGGL(tstp_kernel, dim3(d.H[4], B), dim3(256), 0, st, P[i_fu], stats, d.W[4], 2048, d.H[4]);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(seg_kernel, dim3(EMB, B), dim3(256), 0, st, stats, h->dev + h->seg_w, h->dev + h->seg_b, emb, 40960);

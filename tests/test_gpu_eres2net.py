@@ -79,3 +79,16 @@ def test_wave_to_embedding_and_cosine(model_and_sd, sd2):
     sc = se.cosine_scores(embs, embs[0])
     for i in range(3):
         assert abs(sc[i] - orc.cosine_similarity(embs[i], embs[0])) < 1e-5
+
+
+def test_fuse34_on_the_x3_core_vs_oracle(model_and_sd, monkeypatch):
+    """the final AFF (fuse34, C = 2048) runs on the split-f16 x3 core from 8192 stage-4 rows on (benchmark batches); forced here at
+    sizes the fp64 oracle finishes quickly, same 1e-4 bar as the fp32-core path (graph replay would bypass the switch: new shapes)"""
+    from oracle import eres2netv2_oracle as eo
+    model, sd64 = model_and_sd
+    monkeypatch.setenv("TDX_ERES_AFF34_ROWS", "1")
+    for (B, F) in [(2, 206), (3, 109)]:
+        feat = torch.randn(B, F, 80, generator=torch.Generator().manual_seed(100 + F)) * 2.0
+        ref = eo.eres2netv2_forward(feat.double(), sd64)
+        out = model.embed_features(feat.to(dev))
+        assert rel_l2(out, ref) < 1e-4 and cosd(out, ref) < 1e-3, (B, F, rel_l2(out, ref))

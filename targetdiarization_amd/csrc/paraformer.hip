@@ -81,6 +81,51 @@ __global__ __launch_bounds__(256) void pf_layernorm_planes_kernel_t(const float*
     if (m >= M) return;
     const int lane = threadIdx.x & 63;
     const float* r = x + m * ld;
+    if (C == Cpad && (C & 511) == 0 && C / 512 <= NCH && (ld & 3) == 0) {
+        // the common shapes (512 channels: every encoder / decoder layer but the first; 2048: the decoder's FFN norm): ONE pass — each lane
+        // loads its chunks of 8 consecutive values (32 B per lane and chunk: the wave reads 2-KB lines), statistics from registers (mean,
+        // then the centred sum of squares: the same two-pass formula as below)
+        const int nc = C / 512;
+        float xv[NCH][8];
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            if (i < nc) {
+                const f32x4 a0 = ldg4(r + (lane + 64 * i) * 8), a1 = ldg4(r + (lane + 64 * i) * 8 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { xv[i][j] = a0[j]; xv[i][4 + j] = a1[j]; s1 += a0[j] + a1[j]; }
+            }
+        }
+        const float mean1 = wave_sum(s1) / (float)C;
+        float q1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+            if (i < nc) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = xv[i][j] - mean1; q1 = fmaf(d, d, q1); }
+            }
+        const float rstd1 = 1.0f / sqrtf(wave_sum(q1) / (float)C + eps);
+        float mu1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+            if (i < nc) {
+                const int c0 = (lane + 64 * i) * 8;
+                const f32x4 g0 = ldg4(g + c0), g1 = ldg4(g + c0 + 4), b0 = ldg4(b + c0), b1 = ldg4(b + c0 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xv[i][j] = (xv[i][j] - mean1) * rstd1 * g0[j] + b0[j];
+                    xv[i][4 + j] = (xv[i][4 + j] - mean1) * rstd1 * g1[j] + b1[j];
+                    mu1 = fmaxf(mu1, fmaxf(fabsf(xv[i][j]), fabsf(xv[i][4 + j])));
+                }
+            }
+        float inv1;
+        const float sc1 = h3_row_scale(h3_wave_max(mu1), inv1);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+            if (i < nc) h3_store_chunk(hp + m * (4L * Cpad) + (lane + 64 * i) * 32, xv[i], sc1);
+        if (lane == 0) hs[m] = inv1;
+        return;
+    }
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += r[c];
     const float mean = wave_sum(s) / (float)C;
@@ -116,6 +161,25 @@ __global__ __launch_bounds__(256) void pf_softmax_kernel(float* __restrict__ sc,
     if (r >= S) return;
     const int lane = threadIdx.x & 63;
     float* row = sc + ((long)z * Sp + r) * Sp;
+    if (Sp == 512) {
+        // 30 s segments (T <= 512): the row lives in registers — one read (32 B per lane), one write, instead of three passes of 4-B accesses
+        f32x4 a0 = ldg4(row + lane * 8), a1 = ldg4(row + lane * 8 + 4);
+        float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        float mx1 = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { if (lane * 8 + j >= S) v[j] = -INFINITY; mx1 = fmaxf(mx1, v[j]); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx1 = fmaxf(mx1, __shfl_xor(mx1, o, 64));
+        float s1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] = lane * 8 + j < S ? expf(v[j] - mx1) : 0.f; s1 += v[j]; }
+        const float inv1 = 1.0f / wave_sum(s1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a0[j] = v[j] * inv1; a1[j] = v[4 + j] * inv1; }
+        *reinterpret_cast<f32x4*>(row + lane * 8) = a0;
+        *reinterpret_cast<f32x4*>(row + lane * 8 + 4) = a1;
+        return;
+    }
     float mx = -INFINITY;
     for (int c = lane; c < S; c += 64) mx = fmaxf(mx, row[c]);
 #pragma unroll

@@ -1232,7 +1232,7 @@ int tdx_mf2_forward(tdx_mf2* h, const float* wav, int B, int T, float* out, void
         if (tdx::launch_gemm_h3<false>(g, 2, e, st) != hipSuccess) return tdx::fail_hip(hipGetLastError(), __FILE__, __LINE__);
     }
     float* D = t;        // [2][M][16]
-    hipLaunchKernelGGL(decoder_dot_kernel, rows4(2 * M), dim3(256), 0, st, EM, h->decT, D, 2 * M);
+    hipLaunchKernelGGL(decoder_dot_kernel, dim3((unsigned)((2 * M + 4 * DEC_ROWS - 1) / (4 * DEC_ROWS))), dim3(256), 0, st, EM, h->decT, D, 2 * M);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(decoder_ola_kernel, dim3((unsigned)(((long)B * 2 * T + 255) / 256)), dim3(256), 0, st, D, out, B, S, T);
     LAUNCH_CHECK();

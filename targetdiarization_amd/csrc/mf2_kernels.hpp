@@ -554,28 +554,52 @@ __global__ __launch_bounds__(256) void kvu_reduce_kernel(const float* __restrict
 //  D[z][m][t] = sum_c EM[z][m][c]*wdec[c][t]  (one wave per token row; wdT [16][512])
 //  out[b][k][tau] = D[k][b,s=tau/8][tau%8] + D[k][b,s-1][tau%8+8], zero-padded/trimmed to T
 // ---------------------------------------------------------------------------------------
+constexpr int DEC_ROWS = 8;        // token rows per wave: the 16 x 512 taps stay in registers (128 VGPRs) across them
 __global__ __launch_bounds__(256) void decoder_dot_kernel(const float* __restrict__ EM, const float* __restrict__ wdT,
                                                            float* __restrict__ D, long rows) {
-    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= rows) return;
+    const long m0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * DEC_ROWS;
+    if (m0 >= rows) return;
     const int lane = threadIdx.x & 63;
-    const float4 a0 = *reinterpret_cast<const float4*>(EM + m * 512 + lane * 4);
-    const float4 a1 = *reinterpret_cast<const float4*>(EM + m * 512 + 256 + lane * 4);
-    float d[16];
+    float4 w0[16], w1[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-        const float4 w0 = *reinterpret_cast<const float4*>(wdT + t * 512 + lane * 4);
-        const float4 w1 = *reinterpret_cast<const float4*>(wdT + t * 512 + 256 + lane * 4);
-        float v = a0.x * w0.x;
-        v = fmaf(a0.y, w0.y, v); v = fmaf(a0.z, w0.z, v); v = fmaf(a0.w, w0.w, v);
-        v = fmaf(a1.x, w1.x, v); v = fmaf(a1.y, w1.y, v); v = fmaf(a1.z, w1.z, v); v = fmaf(a1.w, w1.w, v);
-        d[t] = wave_sum(v);
+        w0[t] = *reinterpret_cast<const float4*>(wdT + t * 512 + lane * 4);
+        w1[t] = *reinterpret_cast<const float4*>(wdT + t * 512 + 256 + lane * 4);
     }
-    if (lane < 16) {
-        float v = d[0];
+    // lane -> tap after the transposed reduction below: bit 5 of the lane picks taps 8-15, bit 4 the upper four of those, ...
+    const int tap = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+    float4 a0 = *reinterpret_cast<const float4*>(EM + m0 * 512 + lane * 4);
+    float4 a1 = *reinterpret_cast<const float4*>(EM + m0 * 512 + 256 + lane * 4);
+#pragma unroll 1
+    for (int r = 0; r < DEC_ROWS; ++r) {
+        const long m = m0 + r;
+        if (m >= rows) break;
+        const long mn = min(m + 1, rows - 1);                 // next row requested before this row's arithmetic
+        const float4 n0 = *reinterpret_cast<const float4*>(EM + mn * 512 + lane * 4);
+        const float4 n1 = *reinterpret_cast<const float4*>(EM + mn * 512 + 256 + lane * 4);
+        float d[16];
 #pragma unroll
-        for (int t = 1; t < 16; ++t) v = (lane == t) ? d[t] : v;
-        D[m * 16 + lane] = v;
+        for (int t = 0; t < 16; ++t) {
+            float v = a0.x * w0[t].x;
+            v = fmaf(a0.y, w0[t].y, v); v = fmaf(a0.z, w0[t].z, v); v = fmaf(a0.w, w0[t].w, v);
+            v = fmaf(a1.x, w1[t].x, v); v = fmaf(a1.y, w1[t].y, v); v = fmaf(a1.z, w1[t].z, v); v = fmaf(a1.w, w1[t].w, v);
+            d[t] = v;
+        }
+        // 16 sums over 64 lanes as a transposed butterfly: every exchange halves the number of taps a lane still carries
+        // (8 + 4 + 2 + 1 exchanges), two more fold the four lanes that end up with the same tap: 17 exchanges instead of 16 x 6
+        float e8[8], e4[4], e2[2];
+        const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float send = b5 ? d[j] : d[8 + j], keep = b5 ? d[8 + j] : d[j]; e8[j] = keep + __shfl_xor(send, 32, 64); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float send = b4 ? e8[j] : e8[4 + j], keep = b4 ? e8[4 + j] : e8[j]; e4[j] = keep + __shfl_xor(send, 16, 64); }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const float send = b3 ? e4[j] : e4[2 + j], keep = b3 ? e4[2 + j] : e4[j]; e2[j] = keep + __shfl_xor(send, 8, 64); }
+        float v = (b2 ? e2[1] : e2[0]) + __shfl_xor(b2 ? e2[0] : e2[1], 4, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 1, 64);
+        if ((lane & 3) == 0) D[m * 16 + tap] = v;
+        a0 = n0; a1 = n1;
     }
 }
 
